@@ -1,0 +1,187 @@
+/*
+ * ldx.h -- C ABI of the MI355X (gfx950) pairwise-LD engine.
+ *
+ * Drop-in boundary for the hot path of PlatonB/ld-tools: everything the reference does in
+ * backend/calc_ld.py:3-99, batched over the pair loops that drive it
+ * (ld_triangle.py:133-230, ld_area.py:152-276).  The reference is pure Python and has no FFI
+ * of its own; the binding a maintainer adds is the ctypes stub shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no C++ types, no exceptions cross the boundary.
+ *   - every function returns 0 on success or a negative LDX_E_* code; ldx_last_error() gives
+ *     the message of the last failure on the calling thread.
+ *   - `_dev` entry points take DEVICE pointers (e.g. torch tensors' data_ptr()) and a
+ *     hipStream_t passed as void* (NULL = the null stream).  They enqueue work and return;
+ *     they never allocate, free or synchronise.  The caller owns every buffer.
+ *   - `_host` entry points take HOST pointers, run the same kernels on the current device and
+ *     synchronise before returning.  There is no CPU fallback anywhere in this library.
+ *
+ * Packed panel layout in HBM ("tiled plane")
+ *   A plane holds one bit per (SNP, haplotype).  Rows are grouped into slabs of LDX_SLAB_ROWS
+ *   SNPs; the haplotype axis is cut into chunks of 128 haplotypes (16 bytes).  Element
+ *   (slab s, chunk c, row r) is the 16-byte group at byte offset
+ *       ((s * n_chunks + c) * LDX_SLAB_ROWS + r) * 16,
+ *   bit (h % 128) of it (little-endian, 32-bit words) being haplotype h = 128*c + (h % 128) of
+ *   SNP 128*s + r.  One slab is therefore a contiguous n_chunks*2 KiB image that a workgroup
+ *   copies linearly into LDS, and 8 consecutive SNPs of one chunk are 128 contiguous bytes that a
+ *   wavefront fetches with scalar loads.  Pad bits and pad rows are zero.
+ *   The `alt` plane has bit = 1 where the allele code is 1, the `ref` plane where it is 0
+ *   (calc_ld.py:37-40 counts them separately; any other code is in neither plane).
+ */
+#ifndef LDX_H
+#define LDX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LDX_VERSION 100            /* 0.1.0 */
+#define LDX_SLAB_ROWS 128u         /* SNP rows per slab == SNP columns per j-tile */
+#define LDX_GROUP_ROWS 8u          /* SNP rows a wavefront pairs against one j-tile per unit */
+#define LDX_CHUNK_HAPS 128u        /* haplotypes per 16-byte chunk */
+#define LDX_UNIT_PAIRS (LDX_SLAB_ROWS * LDX_GROUP_ROWS)   /* 1024 result cells per unit */
+#define LDX_MAX_HAPS 10240u        /* one j-tile (128 rows, all chunks) must fit 160 KiB of LDS */
+
+/* error codes */
+#define LDX_OK 0
+#define LDX_E_ARG (-1)             /* bad argument (null pointer, size out of range, ...) */
+#define LDX_E_HIP (-2)             /* a HIP runtime call failed; see ldx_last_error() */
+#define LDX_E_UNSUPPORTED (-3)     /* n_hap > LDX_MAX_HAPS, wrong device architecture, ... */
+#define LDX_E_OVERFLOW (-4)        /* hit buffer too small (ldx_area_*): count is still returned */
+
+/* per-pair flag bits: which results are the reference's *int* 0 rather than a float */
+#define LDX_FLAG_DPRIME_INT0 1u    /* calc_ld.py:68-69,75-76 (ZeroDivisionError branch) */
+#define LDX_FLAG_RSQ_INT0 2u       /* calc_ld.py:89-90 (unrounded d_prime == 0) */
+
+/* measures (ld_triangle -l / ld_area -l: ld_triangle_cli_en.py:52, ld_area_cli_en.py:50) */
+#define LDX_MEASURE_RSQ 0
+#define LDX_MEASURE_DPRIME 1
+
+/* One result cell of the canonical 8-byte/pair output: round(r_square, 4) and round(d_prime, 4)
+ * of calc_ld.py:94-95 as the float32 nearest to k/10^4.  A value that is the reference's int 0
+ * is stored as -0.0f (sign bit set), a float 0.0 as +0.0f, so str() can be reproduced. */
+typedef struct { float r_square; float d_prime; } ldx_ld32;
+typedef struct { double r_square; double d_prime; } ldx_ld64;   /* unrounded, for parity checks */
+
+/* one ld_area hit (ld_area.py:261-271): query/opposing SNP row indices and rounded values */
+typedef struct {
+    uint32_t query;      /* row index of var_1 (the query) in the panel */
+    uint32_t oppos;      /* row index of var_2 (the opposing variant) */
+    float r_square;      /* as ldx_ld32 */
+    float d_prime;
+} ldx_hit;
+
+/* ---- library / device ---------------------------------------------------------------- */
+int ldx_version(void);
+const char *ldx_last_error(void);
+int ldx_device_count(void);                 /* number of visible HIP devices, <0 on error */
+int ldx_device_arch(int device, char *buf, size_t buflen);   /* e.g. "gfx950" */
+
+/* ---- geometry helpers (pure arithmetic, usable without a GPU) ------------------------- */
+uint32_t ldx_n_slabs(uint32_t n_snps);                     /* ceil(n_snps / 128) */
+uint32_t ldx_n_chunks(uint32_t n_hap);                     /* ceil(n_hap / 128) */
+size_t ldx_plane_bytes(uint32_t n_snps, uint32_t n_hap);   /* bytes of one tiled plane */
+uint32_t ldx_padded_snps(uint32_t n_snps);                 /* n_slabs * 128 */
+/* Triangle work units.  Unit u of the strict lower triangle pairs the 8 rows of group g with the
+ * 128 columns of j-tile t, u = t*G - 8*t*(t-1) + (g - 16*t), G = padded_snps/8, g >= 16*t.  Result
+ * cell (row i, column j), i > j, lives at element u*1024 + (i % 8)*128 + (j % 128) of the strip
+ * output, t = j/128, g = i/8. */
+uint64_t ldx_triangle_units(uint32_t n_snps);
+uint64_t ldx_triangle_unit_of(uint32_t n_snps, uint32_t row, uint32_t col);  /* requires row > col */
+uint64_t ldx_triangle_tile_base(uint32_t n_snps, uint32_t tile);             /* first unit of j-tile */
+
+/* ---- packing: the genotype lists of ld_triangle.py:160-186 / ld_area.py:182-187,230-235 ---- */
+/* codes: int8 [n_snps][ld_codes], 1 = ALT, 0 = REF, anything else = neither (None, 2nd ALT...).
+ * alt/ref: tiled planes of ldx_plane_bytes(); ref may be NULL.  acnt/rcnt: uint32 [padded_snps]
+ * = per-SNP counts of code 1 / code 0 (calc_ld.py:37-40); rcnt may be NULL iff ref is. */
+int ldx_pack_codes_dev(const int8_t *codes, uint32_t n_snps, uint32_t n_hap, size_t ld_codes,
+                       void *alt, void *ref, uint32_t *acnt, uint32_t *rcnt, void *stream);
+/* row-major bit planes (uint32 words, W32 = ld_words per row, little-endian bit order) -> tiled */
+int ldx_tile_plane_dev(const uint32_t *rowmajor, uint32_t n_snps, uint32_t n_hap, size_t ld_words,
+                       void *tiled, uint32_t *cnt, void *stream);
+/* per-SNP frequency vectors used by the epilogue: fa = a/n, fr = r/n, q = fa*fr (calc_ld.py:41-44,
+ * and the first product of :87-88).  double [padded_snps] each. */
+int ldx_snp_stats_dev(const uint32_t *acnt, const uint32_t *rcnt, uint32_t n_snps, uint32_t n_hap,
+                      double *fa, double *fr, double *q, void *stream);
+
+/* round(a/n, 4) per SNP as a double: var_1/var_2_alt_freq of calc_ld.py:96-97 and the query's alt_freq of
+ * ld_area.py:188-189.  freq4: double [n_snps]. */
+int ldx_alt_freq4_dev(const uint32_t *acnt, uint32_t n_snps, uint32_t n_hap, double *freq4, void *stream);
+
+/* ---- bit-exact contract: the alt/alt haplotype count of calc_ld.py:32 ------------------ */
+/* n11[i][j] = popcount(alt_i[row i] & alt_j[row j]) for all rows of panel I against all rows of
+ * panel J (may be the same plane).  n11 is dense row-major uint32 [n_i][ld]. */
+int ldx_pair_counts_dev(const void *alt_i, uint32_t n_i, const void *alt_j, uint32_t n_j,
+                        uint32_t n_hap, uint32_t *n11, size_t ld, void *stream);
+
+/* ---- the epilogue alone: calc_ld.py:33-97 from the six integers ------------------------ */
+/* Element k uses (n, n11[k], a1[k], r1[k], a2[k], r2[k]).  Any output may be NULL. */
+int ldx_ld_from_counts_dev(uint32_t n, size_t m, const uint32_t *n11, const uint32_t *a1,
+                           const uint32_t *r1, const uint32_t *a2, const uint32_t *r2,
+                           ldx_ld64 *raw, ldx_ld32 *rounded, uint8_t *flags, void *stream);
+
+/* ---- ld_triangle: all row > col pairs (ld_triangle.py:133-230) ------------------------- */
+/* Computes work units [unit_begin, unit_end) (clamped to ldx_triangle_units()).  var_1 = row,
+ * var_2 = col as at ld_triangle.py:193-194.  Outputs are indexed from unit_begin:
+ * out[(u - unit_begin)*1024 + ...].  Cells with row <= col or row >= n_snps are written as zero.
+ * out_raw / out_n11 may be NULL.  fa/fr/q from ldx_snp_stats_dev. */
+int ldx_triangle_dev(const void *alt, const double *fa, const double *fr, const double *q,
+                     uint32_t n_snps, uint32_t n_hap, uint64_t unit_begin, uint64_t unit_end,
+                     ldx_ld32 *out, ldx_ld64 *out_raw, uint32_t *out_n11, void *stream);
+/* Strip output -> dense row-major float32 [n_rows][ld] matrix of one measure with the
+ * ld_two_dim semantics of ld_triangle.py:114,223-230: cell = rounded measure, or 0 when
+ * row <= col or (has_thres and rounded measure < thres).  Rows [row_begin, row_end). */
+int ldx_triangle_dense_dev(const ldx_ld32 *strips, uint32_t n_snps, int measure, int has_thres,
+                           double thres, uint32_t row_begin, uint32_t row_end, float *dense,
+                           size_t ld, void *stream);
+
+/* ---- ld_area: windowed scan around query SNPs (ld_area.py:152-276) --------------------- */
+/* positions: int64 [n_snps] ascending 1-based coordinates (VCF order).  queries: uint32 row
+ * indices [n_query].  For each query q the opposing set is o != q with
+ * max(0, pos_q - flank) < pos_o <= pos_q + flank (pysam fetch semantics, ld_area.py:174-177,
+ * 215-217).  var_1 = query, var_2 = opposing (ld_area.py:242-243).  A hit is kept when the
+ * ROUNDED measure >= thres (ld_area.py:248).  `queries` must ascend (so their positions do).
+ * hits: capacity hit_cap, written in arbitrary order (sort by (query, oppos) for VCF order).
+ * Wavefronts reserve hit slots in batches of 256: *n_hits (device uint64) receives the number of
+ * slots RESERVED, unused slots carry query == UINT32_MAX and must be skipped.  If *n_hits exceeds
+ * hit_cap only the first hit_cap slots were stored: retry with a larger buffer.
+ * workspace: ldx_area_workspace_bytes() bytes, 256-byte aligned, scratch for the gathered query
+ * panel and the unit plan. */
+int ldx_area_dev(const void *alt, const double *fa, const double *fr, const double *q,
+                 uint32_t n_snps, uint32_t n_hap, const int64_t *positions,
+                 const uint32_t *queries, uint32_t n_query, int64_t flank, int measure,
+                 double thres, ldx_hit *hits, uint64_t hit_cap, uint64_t *n_hits, void *workspace,
+                 size_t workspace_bytes, void *stream);
+size_t ldx_area_workspace_bytes(uint32_t n_snps, uint32_t n_hap, uint32_t n_query);
+
+/* ---- synthetic panels: deterministic, identical on host and device ------ */
+/* codes int8 [n_snps][ld_codes] receive global SNPs [snp_offset, snp_offset + n_snps) (a rank's
+ * shard).  thresholds: per-SNP ALT probability * 2^64 (computed on the host, see
+ * ld_tools_amd/synth.py), covering whole LD blocks: thresholds[k] belongs to global SNP
+ * (snp_offset / block_len) * block_len + k, up to the end of the block holding the last SNP.
+ * rho_thr: within-block copy probability * 2^64.  miss_thr: probability * 2^64 of code 2. */
+int ldx_synth_codes_dev(int8_t *codes, uint32_t n_snps, uint32_t n_hap, size_t ld_codes,
+                        uint64_t seed, const uint64_t *thresholds, uint64_t rho_thr,
+                        uint32_t block_len, uint64_t miss_thr, uint32_t snp_offset, void *stream);
+
+/* ---- host-pointer conveniences (same kernels; allocate, copy, synchronise) ------------- */
+/* calc_ld for ONE pair of code vectors of lengths h1, h2 (zip semantics of calc_ld.py:30-31:
+ * n = min(h1, h2) for the haplotype count, allele counts over the full vectors).
+ * counts[6] = {n, n11, a1, r1, a2, r2}; raw/rounded as above; freq4[2] = round4(fa1), round4(fa2). */
+int ldx_calc_ld_host(const int8_t *g1, uint32_t h1, const int8_t *g2, uint32_t h2,
+                     uint32_t counts[6], ldx_ld64 *raw, ldx_ld64 *rounded, double freq4[2],
+                     uint8_t *flags);
+
+/* ---- instrumentation ------------------------------------------------------------------- */
+/* Peak-rate probe for the v_and_b32 + v_bcnt_u32_b32 pair (the inner loop's two instructions):
+ * runs `iters` rounds of 64 AND + 64 BCNT per lane on `blocks` x `threads` threads (threads a multiple
+ * of 64, <= 1024), no memory traffic, and writes a checksum to sink[blocks*threads]. */
+int ldx_probe_andpop_dev(uint32_t *sink, uint32_t blocks, uint32_t threads, uint32_t iters, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LDX_H */

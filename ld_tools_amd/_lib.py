@@ -1,0 +1,96 @@
+"""ctypes binding of libldx.so (include/ldx.h).  No fallback: a missing library is an error.
+
+The library is built in-tree by ``python -m ld_tools_amd.build`` (``__graft_entry__.build()``
+does it).  If it is missing and hipcc is present it is built on first import; if that fails,
+the import raises -- there is no CPU path in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+from . import build as _build
+
+LIB_PATH = Path(__file__).resolve().parent / "libldx.so"
+
+# constants of include/ldx.h
+SLAB_ROWS = 128
+GROUP_ROWS = 8
+UNIT_PAIRS = SLAB_ROWS * GROUP_ROWS
+MAX_HAPS = 10240
+FLAG_DPRIME_INT0 = 1
+FLAG_RSQ_INT0 = 2
+MEASURES = {"r_square": 0, "d_prime": 1}
+INVALID_ROW = 0xFFFFFFFF
+
+E_NAMES = {-1: "LDX_E_ARG", -2: "LDX_E_HIP", -3: "LDX_E_UNSUPPORTED", -4: "LDX_E_OVERFLOW"}
+
+
+class LdxError(RuntimeError):
+    pass
+
+
+def _load() -> C.CDLL:
+    # an existing library is loaded as it is (ranks of one job must not rebuild it under each other);
+    # `python -m ld_tools_amd.build` / __graft_entry__.build() refresh a stale one explicitly
+    if not LIB_PATH.exists():
+        try:
+            _build.build(verbose=False)
+        except Exception as exc:  # noqa: BLE001
+            if not LIB_PATH.exists():
+                raise ImportError(
+                    f"ld_tools_amd: {LIB_PATH} is missing and could not be built ({exc}); "
+                    "run `python -m ld_tools_amd.build` on a machine with hipcc. "
+                    "There is no CPU fallback.") from exc
+    return C.CDLL(str(LIB_PATH))
+
+
+lib = _load()
+
+_vp, _u32, _u64, _i64, _sz, _int, _dbl = (C.c_void_p, C.c_uint32, C.c_uint64, C.c_int64, C.c_size_t,
+                                          C.c_int, C.c_double)
+
+# name -> (restype, argtypes); also the list the symbol test walks (kept in sync with ldx.h)
+SIGNATURES = {
+    "ldx_version": (_int, []),
+    "ldx_last_error": (C.c_char_p, []),
+    "ldx_device_count": (_int, []),
+    "ldx_device_arch": (_int, [_int, C.c_char_p, _sz]),
+    "ldx_n_slabs": (_u32, [_u32]),
+    "ldx_n_chunks": (_u32, [_u32]),
+    "ldx_plane_bytes": (_sz, [_u32, _u32]),
+    "ldx_padded_snps": (_u32, [_u32]),
+    "ldx_triangle_units": (_u64, [_u32]),
+    "ldx_triangle_unit_of": (_u64, [_u32, _u32, _u32]),
+    "ldx_triangle_tile_base": (_u64, [_u32, _u32]),
+    "ldx_pack_codes_dev": (_int, [_vp, _u32, _u32, _sz, _vp, _vp, _vp, _vp, _vp]),
+    "ldx_tile_plane_dev": (_int, [_vp, _u32, _u32, _sz, _vp, _vp, _vp]),
+    "ldx_snp_stats_dev": (_int, [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp]),
+    "ldx_alt_freq4_dev": (_int, [_vp, _u32, _u32, _vp, _vp]),
+    "ldx_pair_counts_dev": (_int, [_vp, _u32, _vp, _u32, _u32, _vp, _sz, _vp]),
+    "ldx_ld_from_counts_dev": (_int, [_u32, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ldx_triangle_dev": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u64, _u64, _vp, _vp, _vp, _vp]),
+    "ldx_triangle_dense_dev": (_int, [_vp, _u32, _int, _int, _dbl, _u32, _u32, _vp, _sz, _vp]),
+    "ldx_area_dev": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _u32, _i64, _int, _dbl, _vp, _u64,
+                            _vp, _vp, _sz, _vp]),
+    "ldx_area_workspace_bytes": (_sz, [_u32, _u32, _u32]),
+    "ldx_synth_codes_dev": (_int, [_vp, _u32, _u32, _sz, _u64, _vp, _u64, _u32, _u64, _u32, _vp]),
+    "ldx_calc_ld_host": (_int, [_vp, _u32, _vp, _u32, _vp, _vp, _vp, _vp, _vp]),
+    "ldx_probe_andpop_dev": (_int, [_vp, _u32, _u32, _u32, _vp]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)          # AttributeError here == header and library out of sync
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def check(rc: int, what: str = "") -> None:
+    """Raise LdxError for a negative return code of an ldx_* call."""
+    if rc < 0:
+        msg = lib.ldx_last_error().decode("utf-8", "replace")
+        raise LdxError(f"{what or 'ldx call'} failed: {E_NAMES.get(rc, rc)}: {msg}")
+
+
+def version() -> int:
+    return lib.ldx_version()

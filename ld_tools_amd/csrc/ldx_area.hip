@@ -1,0 +1,270 @@
+// Windowed scan around query SNPs: the loop of ld_area.py:152-276 on the packed panel.
+//
+// Three launches on the caller's stream, all inside ldx_area_dev:
+//   1. area_gather: copy the query rows into a compact tiled "query panel" (so the scalar side of the
+//      pair kernel walks consecutive rows), with their positions and frequency vectors.
+//   2. area_plan:   per j-tile of the panel, the range of query groups whose window can reach the tile
+//      (queries ascend by position, so it is one binary search each way), then a prefix sum -> unit list.
+//   3. area_scan:   persistent workgroups over equal shares of the unit list; per unit 8 queries x 128
+//      opposing rows through the same LDS-tile / scalar-row inner loop as ld_triangle, the fp64 epilogue
+//      with var_1 = query, var_2 = opposing (ld_area.py:242-243), the window / self filter
+//      (ld_area.py:174-177,222), the threshold on the ROUNDED measure (ld_area.py:248) and hit append.
+// Hits are appended through per-wave slot batches (one global atomic per 256 slots); unused slots are
+// marked invalid (query == UINT32_MAX).
+#include "ldx_common.h"
+#include "ldx_tile.h"
+
+namespace ldx {
+
+constexpr uint32_t kBatch = 256;   // hit slots a wave reserves per atomic
+constexpr uint32_t kInvalid = 0xFFFFFFFFu;
+
+struct AreaWs {          // carved out of the caller's workspace
+    uint4 *qalt;         // tiled plane of the gathered query rows
+    int64_t *qpos;       // [q_pad]  position of query k (INT64_MAX beyond n_query)
+    uint32_t *qrow;      // [q_pad]  panel row of query k
+    double *qfa, *qfr, *qq;
+    uint32_t *g_begin;   // [T] first query group of tile t
+    uint64_t *unit_base; // [T + 1] prefix sum of group counts
+};
+
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+static size_t carve(AreaWs &w, void *base, uint32_t n_snps, uint32_t n_hap, uint32_t n_query)
+{
+    const uint32_t qpad = ldx_padded_snps(n_query), T = ldx::n_slabs(n_snps);
+    size_t off = 0;
+    char *b = (char *)base;
+    auto take = [&](size_t bytes) { void *p = b ? b + off : nullptr; off = align_up(off + bytes, 256); return p; };
+    w.qalt = (uint4 *)take(ldx_plane_bytes(n_query, n_hap));
+    w.qpos = (int64_t *)take(qpad * sizeof(int64_t));
+    w.qrow = (uint32_t *)take(qpad * sizeof(uint32_t));
+    w.qfa = (double *)take(qpad * sizeof(double));
+    w.qfr = (double *)take(qpad * sizeof(double));
+    w.qq = (double *)take(qpad * sizeof(double));
+    w.g_begin = (uint32_t *)take(T * sizeof(uint32_t));
+    w.unit_base = (uint64_t *)take((T + 1) * sizeof(uint64_t));
+    return off;
+}
+
+// one wavefront per query row: copy its chunks from the panel plane into the query plane
+__global__ void __launch_bounds__(256) area_gather_kernel(const uint4 *__restrict__ alt, const double *__restrict__ fa,
+                                                          const double *__restrict__ fr, const double *__restrict__ q,
+                                                          const int64_t *__restrict__ pos,
+                                                          const uint32_t *__restrict__ queries, uint32_t n_query,
+                                                          uint32_t q_pad, uint32_t nchunks, AreaWs w)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t k = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (k >= q_pad) return;
+    const bool real = k < n_query;
+    const uint32_t row = real ? queries[k] : 0u;
+    const uint4 zero = {0u, 0u, 0u, 0u};
+    const uint4 *src = alt + ((size_t)(row / kSlab) * nchunks) * kSlab + (row % kSlab);
+    uint4 *dst = w.qalt + ((size_t)(k / kSlab) * nchunks) * kSlab + (k % kSlab);
+    for (uint32_t c = lane; c < nchunks; c += 64u) dst[(size_t)c * kSlab] = real ? src[(size_t)c * kSlab] : zero;
+    if (lane == 0) {
+        w.qpos[k] = real ? pos[row] : INT64_MAX;
+        w.qrow[k] = real ? row : kInvalid;
+        w.qfa[k] = real ? fa[row] : 0.0;
+        w.qfr[k] = real ? fr[row] : 0.0;
+        w.qq[k] = real ? q[row] : 0.0;
+    }
+}
+
+// single workgroup: per tile the query-group range, then an exclusive scan (T <= a few thousand)
+__global__ void __launch_bounds__(1024) area_plan_kernel(const int64_t *__restrict__ pos, uint32_t n_snps, uint32_t T,
+                                                         uint32_t n_query, int64_t flank, AreaWs w)
+{
+    __shared__ uint64_t carry;
+    __shared__ uint32_t wsum[16];
+    if (threadIdx.x == 0) { carry = 0; w.unit_base[0] = 0; }
+    __syncthreads();
+    for (uint32_t t0 = 0; t0 < T; t0 += 1024u) {
+        const uint32_t t = t0 + threadIdx.x;
+        uint32_t cnt = 0;
+        if (t < T) {
+            const uint32_t last = (t + 1u) * kSlab < n_snps ? (t + 1u) * kSlab - 1u : n_snps - 1u;
+            const int64_t pmin = pos[t * kSlab], pmax = pos[last];
+            // qa = first query with pos_q + flank >= pmin ; qb = first query with max(0, pos_q - flank) >= pmax
+            uint32_t lo = 0, hi = n_query;
+            while (lo < hi) { const uint32_t m = (lo + hi) / 2; if (w.qpos[m] + flank >= pmin) hi = m; else lo = m + 1; }
+            const uint32_t qa = lo;
+            lo = 0; hi = n_query;
+            while (lo < hi) {
+                const uint32_t m = (lo + hi) / 2;
+                int64_t low = w.qpos[m] - flank;
+                if (low < 0) low = 0;
+                if (low >= pmax) hi = m; else lo = m + 1;
+            }
+            const uint32_t qb = lo;
+            if (qb > qa) {
+                const uint32_t ga = qa / kGroup, gb = (qb + kGroup - 1) / kGroup;
+                w.g_begin[t] = ga;
+                cnt = gb - ga;
+            } else {
+                w.g_begin[t] = 0;
+            }
+        }
+        // workgroup inclusive scan of cnt
+        uint32_t x = cnt;
+        const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(x, off); if (lane >= (uint32_t)off) x += y; }
+        if (lane == 63) wsum[wv] = x;
+        __syncthreads();
+        uint32_t pre = 0;
+        for (uint32_t k = 0; k < wv; ++k) pre += wsum[k];
+        const uint64_t incl = carry + pre + x;
+        if (t < T) w.unit_base[t + 1] = incl;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = incl;
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(kThreads)
+area_scan_kernel(const uint4 *__restrict__ alt, const uint4 *__restrict__ qalt, const double *__restrict__ fa,
+                 const double *__restrict__ fr, const int64_t *__restrict__ pos, const int64_t *__restrict__ qpos,
+                 const uint32_t *__restrict__ qrows, const double *__restrict__ qfa, const double *__restrict__ qfr,
+                 const double *__restrict__ qq, const uint32_t *__restrict__ g_begin,
+                 const uint64_t *__restrict__ unit_base, uint32_t n_snps, uint32_t T, uint32_t nchunks, double n,
+                 int64_t flank, int measure, double k_thres, ldx_hit *__restrict__ hits, uint64_t hit_cap,
+                 unsigned long long *__restrict__ n_hits)
+{
+    extern __shared__ uint4 lds[];
+    uint4 *jt = lds;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t total = unit_base[T];
+    const uint64_t b0 = total * blockIdx.x / gridDim.x;
+    const uint64_t b1 = total * (blockIdx.x + 1) / gridDim.x;
+
+    // per-wave hit slots: [slot, slot_end) is the unfilled part of the current batch
+    uint64_t slot = 0, slot_end = 0;
+
+    if (b0 < b1) {
+        uint32_t lo = 0, hi = T;   // largest t with unit_base[t] <= b0
+        while (hi - lo > 1) { const uint32_t m = (lo + hi) / 2; if (unit_base[m] <= b0) lo = m; else hi = m; }
+        uint32_t t = lo;
+        uint64_t u = b0;
+        while (u < b1) {   // block-uniform
+            const uint64_t tb = unit_base[t], te = unit_base[t + 1u];
+            if (te <= u) { ++t; continue; }   // empty tile
+            const uint64_t seg_end = b1 < te ? b1 : te;
+            const uint32_t seg_len = (uint32_t)(seg_end - u);
+            __syncthreads();
+            stage_tile(jt, alt + (size_t)t * nchunks * kSlab, nchunks * kSlab);
+            const uint32_t o0 = t * kSlab + lane, o1 = o0 + 64u;
+            const bool ov[2] = {o0 < n_snps, o1 < n_snps};
+            const double fa2[2] = {fa[o0], fa[o1]};
+            const double fr2[2] = {fr[o0], fr[o1]};
+            const int64_t po[2] = {ov[0] ? pos[o0] : 0, ov[1] ? pos[o1] : 0};
+            __syncthreads();
+            const uint32_t gfirst = g_begin[t];
+
+            for (uint32_t k = wave; k < seg_len; k += kWaves) {
+                const uint32_t g = gfirst + (uint32_t)(u + k - tb);   // query group
+                const uint32_t q0 = g * kGroup;
+                const uint4 *ai = qalt + ((size_t)(q0 / kSlab) * nchunks) * kSlab + (q0 % kSlab);
+                Acc acc;
+                count_unit(ai, jt, nchunks, lane, acc);
+#pragma unroll
+                for (int r = 0; r < (int)kGroup; ++r) {
+                    const uint32_t qi = q0 + r;                       // wave-uniform
+                    const uint32_t qrow = qrows[qi];
+                    const int64_t pq = qpos[qi];
+                    int64_t low = pq - flank;
+                    if (low < 0) low = 0;                             // ld_area.py:174-176
+                    const int64_t high = pq + flank;                // ld_area.py:177
+                    const double fa1 = qfa[qi], fr1 = qfr[qi], q1 = qq[qi];
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const uint32_t o = jj ? o1 : o0;
+                        bool keep = qrow != kInvalid && ov[jj] && o != qrow && low < po[jj] && po[jj] <= high;
+                        ldx_ld32 res = {0.0f, 0.0f};
+                        if (keep) {
+                            const LdRaw lr = ld_epilogue((double)acc.v[r][jj] / n, fa1, fr1, q1, fa2[jj], fr2[jj]);
+                            const double kr = round4_k(lr.rsq), kd = round4_k(lr.dprime);
+                            keep = (measure == LDX_MEASURE_RSQ ? kr : kd) >= k_thres;   // ld_area.py:248
+                            res.r_square = encode32(kr, (lr.flags & LDX_FLAG_RSQ_INT0) != 0);
+                            res.d_prime = encode32(kd, (lr.flags & LDX_FLAG_DPRIME_INT0) != 0);
+                        }
+                        const unsigned long long m = __ballot(keep);
+                        if (m) {   // wave-uniform
+                            const uint32_t cnt = __builtin_popcountll(m);
+                            if (slot + cnt > slot_end) {
+                                // close the old batch (mark what is left invalid), open a new one
+                                for (uint64_t s = slot + lane; s < slot_end; s += 64u)
+                                    if (s < hit_cap) hits[s].query = kInvalid;
+                                unsigned long long base = 0;
+                                if (lane == 0) base = atomicAdd(n_hits, (unsigned long long)kBatch);
+                                base = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
+                                       __builtin_amdgcn_readfirstlane((uint32_t)base);
+                                slot = base;
+                                slot_end = base + kBatch;
+                            }
+                            if (keep) {
+                                const uint64_t s = slot + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+                                if (s < hit_cap) hits[s] = ldx_hit{qrow, o, res.r_square, res.d_prime};
+                            }
+                            slot += cnt;
+                        }
+                    }
+                }
+            }
+            u = seg_end;
+            ++t;
+        }
+    }
+    for (uint64_t s = slot + lane; s < slot_end; s += 64u)
+        if (s < hit_cap) hits[s].query = kInvalid;
+}
+
+}  // namespace ldx
+
+using namespace ldx;
+
+extern "C" size_t ldx_area_workspace_bytes(uint32_t n_snps, uint32_t n_hap, uint32_t n_query)
+{
+    AreaWs w;
+    return carve(w, nullptr, n_snps, n_hap, n_query ? n_query : 1);
+}
+
+extern "C" int ldx_area_dev(const void *alt, const double *fa, const double *fr, const double *q, uint32_t n_snps,
+                            uint32_t n_hap, const int64_t *positions, const uint32_t *queries, uint32_t n_query,
+                            int64_t flank, int measure, double thres, ldx_hit *hits, uint64_t hit_cap,
+                            uint64_t *n_hits, void *workspace, size_t workspace_bytes, void *stream)
+{
+    LDX_REQUIRE(alt && fa && fr && q && positions && queries && n_hits && workspace, "null pointer");
+    LDX_REQUIRE(hits || hit_cap == 0, "hits is null but hit_cap > 0");
+    LDX_REQUIRE(n_snps >= 1 && n_hap >= 1 && n_query >= 1 && flank >= 0, "bad shape");
+    LDX_REQUIRE(measure == LDX_MEASURE_RSQ || measure == LDX_MEASURE_DPRIME, "bad measure");
+    LDX_REQUIRE(((uintptr_t)workspace & 255u) == 0, "workspace must be 256-byte aligned");
+    if (n_hap > LDX_MAX_HAPS) {
+        set_error("ldx_area_dev: n_hap %u > LDX_MAX_HAPS %u", n_hap, LDX_MAX_HAPS);
+        return LDX_E_UNSUPPORTED;
+    }
+    AreaWs w;
+    const size_t need = carve(w, workspace, n_snps, n_hap, n_query);
+    LDX_REQUIRE(workspace_bytes >= need, "workspace too small (see ldx_area_workspace_bytes)");
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t qpad = ldx_padded_snps(n_query), T = ldx::n_slabs(n_snps), nch = ldx::n_chunks(n_hap);
+    LDX_HIP(hipMemsetAsync(n_hits, 0, sizeof(uint64_t), s));
+    area_gather_kernel<<<(qpad + 3u) / 4u, 256, 0, s>>>((const uint4 *)alt, fa, fr, q, positions, queries, n_query, qpad,
+                                                       nch, w);
+    LDX_HIP(hipGetLastError());
+    area_plan_kernel<<<1, 1024, 0, s>>>(positions, n_snps, T, n_query, flank, w);
+    LDX_HIP(hipGetLastError());
+    const size_t lds = (size_t)nch * kSlab * 16u;
+    LDX_HIP(hipFuncSetAttribute((const void *)area_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int dev = 0, cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    area_scan_kernel<<<cus, kThreads, lds, s>>>((const uint4 *)alt, w.qalt, fa, fr, positions, w.qpos, w.qrow, w.qfa,
+                                                w.qfr, w.qq, w.g_begin, w.unit_base, n_snps, T, nch, (double)n_hap,
+                                                flank, measure, thres_to_k(thres), hits, hit_cap,
+                                                (unsigned long long *)n_hits);
+    LDX_HIP(hipGetLastError());
+    return LDX_OK;
+}

@@ -1,0 +1,108 @@
+// Shared definitions for the ldx HIP sources (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/ldx.h"
+
+namespace ldx {
+
+constexpr uint32_t kSlab = LDX_SLAB_ROWS;     // 128 SNP rows per slab / j-tile
+constexpr uint32_t kGroup = LDX_GROUP_ROWS;   // 8 SNP rows per wave unit
+constexpr uint32_t kGroupsPerSlab = kSlab / kGroup;   // 16
+
+void set_error(const char *fmt, ...);
+
+// Smallest integer k >= 0 with (double)k / 1e4 >= thres: "rounded value >= thres" (ld_area.py:248,
+// ld_triangle.py:224) becomes the exact integer test k >= thres_to_k(thres).
+double thres_to_k(double thres);
+
+#define LDX_HIP(call)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            ::ldx::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+                             __LINE__);                                                     \
+            return LDX_E_HIP;                                                               \
+        }                                                                                   \
+    } while (0)
+
+#define LDX_REQUIRE(cond, msg)                                     \
+    do {                                                           \
+        if (!(cond)) {                                             \
+            ::ldx::set_error("%s: %s", __func__, msg);             \
+            return LDX_E_ARG;                                      \
+        }                                                          \
+    } while (0)
+
+__host__ __device__ inline uint32_t n_slabs(uint32_t n_snps) { return (n_snps + kSlab - 1) / kSlab; }
+__host__ __device__ inline uint32_t n_chunks(uint32_t n_hap) { return (n_hap + 127u) / 128u; }
+
+// first unit of j-tile t: t*G - 8*t*(t-1), G = groups in the padded panel
+__host__ __device__ inline uint64_t tile_base(uint64_t t, uint64_t G) { return t * G - 8u * t * (t - 1u); }
+
+// ---- the epilogue: calc_ld.py:33-97 mirrored op for op in fp64 (compile with -ffp-contract=off) ----
+// Inputs: f11 = n11/n, and the per-SNP frequencies fa = a/n, fr = r/n, q1 = fa1*fr1.
+// var_1 is the row / query, var_2 the column / opposing variant.
+struct LdRaw {
+    double rsq, dprime;
+    uint32_t flags;
+};
+
+__device__ inline LdRaw ld_epilogue(double f11, double fa1, double fr1, double q1, double fa2, double fr2)
+{
+    LdRaw o;
+    const double p = fa1 * fa2;
+    const double d = f11 - p;                       // calc_ld.py:50 (product rounded, then the difference)
+    const double m1 = fa1 * fr2, m2 = fr1 * fa2;    // :64-65
+    const double dmax = m1 < m2 ? m1 : m2;
+    const double m3 = fr1 * fr2;                    // :71-72  max(-p, -m3) == -min(p, m3)
+    const double dmin = -(p < m3 ? p : m3);
+    const double bound = d >= 0.0 ? dmax : dmin;
+    o.flags = 0;
+    if (bound == 0.0) {                             // :68-69, :75-76  ZeroDivisionError -> int 0
+        o.dprime = 0.0;
+        o.flags |= LDX_FLAG_DPRIME_INT0;
+    } else {
+        o.dprime = d / bound;
+    }
+    if (o.dprime != 0.0) {                          // :86-88  (q1*fa2)*fr2 == ((fa1*fr1)*fa2)*fr2
+        o.rsq = (d * d) / ((q1 * fa2) * fr2);
+    } else {                                        // :89-90
+        o.rsq = 0.0;
+        o.flags |= LDX_FLAG_RSQ_INT0;
+    }
+    return o;
+}
+
+// Python round(x, 4) for finite x >= 0 as the integer k with result == k / 10^4 (calc_ld.py:94-97).
+// x*1e4 == y + e exactly; see oracle/ld_oracle.py:round4 for why deciding on frac(y), then e, is exact.
+__device__ inline double round4_k(double x)
+{
+    const double y = x * 1e4;
+    const double e = __builtin_fma(x, 1e4, -y);
+    double k = __builtin_floor(y);
+    const double f = y - k;
+    const bool odd = (k - 2.0 * __builtin_floor(k * 0.5)) != 0.0;
+    const bool up = (f > 0.5) || (f == 0.5 && (e > 0.0 || (e == 0.0 && odd)));
+    return up ? k + 1.0 : k;
+}
+
+// float32 nearest to k/10^4; an int-0 result carries the sign bit (-0.0f).
+__device__ inline float encode32(double k, bool int0)
+{
+    float v = (float)(k * 1e-4);
+    return int0 ? -0.0f : v;
+}
+
+__device__ inline ldx_ld32 round_pair(const LdRaw &r)
+{
+    ldx_ld32 o;
+    o.r_square = encode32(round4_k(r.rsq), (r.flags & LDX_FLAG_RSQ_INT0) != 0);
+    o.d_prime = encode32(round4_k(r.dprime), (r.flags & LDX_FLAG_DPRIME_INT0) != 0);
+    return o;
+}
+
+}  // namespace ldx

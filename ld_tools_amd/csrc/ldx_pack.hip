@@ -1,0 +1,186 @@
+// Packing of allele codes into the tiled 2-plane SNP x haplotype matrix, per-SNP counts and
+// frequency vectors.  Replaces the per-pair genotype list assembly of
+// ld_triangle.py:160-186 / ld_area.py:182-187,230-235 (each SNP is packed once) and the
+// per-pair list scans of calc_ld.py:37-44 (allele counts are per-SNP constants).
+#include "ldx_common.h"
+
+namespace ldx {
+
+// bit 7 of every byte of v that equals zero (exact per byte)
+__device__ inline uint32_t zero_bytes(uint32_t v)
+{
+    return ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v | 0x7F7F7F7Fu);
+}
+
+// gather bit 7 of the 4 bytes into bits 0..3
+__device__ inline uint32_t gather4(uint32_t f)
+{
+    f >>= 7;   // flags now at bits 0, 8, 16, 24
+    return (f | (f >> 7) | (f >> 14) | (f >> 21)) & 0xFu;
+}
+
+// 16 codes (one uint4 of int8) -> 16 alt bits (code == 1) and 16 ref bits (code == 0)
+__device__ inline void codes16(uint4 v, uint32_t &alt, uint32_t &ref)
+{
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    alt = 0;
+    ref = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        alt |= gather4(zero_bytes(w[k] ^ 0x01010101u)) << (4 * k);
+        ref |= gather4(zero_bytes(w[k])) << (4 * k);
+    }
+}
+
+// One wavefront per SNP row.  Lane l handles haplotypes [1024*s + 16*l, +16) of segment s: a
+// 16-byte coalesced load, 16 alt + 16 ref bits, stored as one uint16 into the tiled planes (8
+// lanes fill one 16-byte chunk).  Counts are reduced across the wave.
+__global__ void __launch_bounds__(256) pack_codes_kernel(const int8_t *__restrict__ codes, uint32_t n_snps,
+                                                         uint32_t n_hap, size_t ld, uint16_t *__restrict__ alt,
+                                                         uint16_t *__restrict__ ref, uint32_t *__restrict__ acnt,
+                                                         uint32_t *__restrict__ rcnt, uint32_t nchunks)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t row = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (row >= n_snps) return;
+    const int8_t *g = codes + (size_t)row * ld;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(g) & 15u) == 0);
+    const uint32_t slab = row / kSlab, rin = row % kSlab;
+    uint32_t ca = 0, cr = 0;
+    for (uint32_t h0 = lane * 16u; h0 < n_hap; h0 += 1024u) {
+        uint32_t a, r;
+        if (aligned && h0 + 16u <= n_hap) {
+            codes16(*reinterpret_cast<const uint4 *>(g + h0), a, r);
+        } else {
+            a = 0;
+            r = 0;
+            for (uint32_t k = 0; k < 16u && h0 + k < n_hap; ++k) {
+                const int8_t c = g[h0 + k];
+                a |= (uint32_t)(c == 1) << k;
+                r |= (uint32_t)(c == 0) << k;
+            }
+        }
+        ca += __builtin_popcount(a);
+        cr += __builtin_popcount(r);
+        const uint32_t chunk = h0 >> 7, sub = (h0 >> 4) & 7u;   // 8 uint16 per 16-byte chunk
+        const size_t idx = (((size_t)slab * nchunks + chunk) * kSlab + rin) * 8u + sub;
+        alt[idx] = (uint16_t)a;
+        if (ref) ref[idx] = (uint16_t)r;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        ca += __shfl_xor(ca, off);
+        cr += __shfl_xor(cr, off);
+    }
+    if (lane == 0) {
+        acnt[row] = ca;
+        if (rcnt) rcnt[row] = cr;
+    }
+}
+
+// row-major bit plane (uint32 words) -> tiled plane; one wavefront per row, lane per 32-bit word
+__global__ void __launch_bounds__(256) tile_plane_kernel(const uint32_t *__restrict__ rowmajor, uint32_t n_snps,
+                                                         uint32_t n_hap, size_t ldw, uint32_t *__restrict__ tiled,
+                                                         uint32_t *__restrict__ cnt, uint32_t nchunks)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t row = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (row >= n_snps) return;
+    const uint32_t nwords = (n_hap + 31u) / 32u;
+    const uint32_t slab = row / kSlab, rin = row % kSlab;
+    uint32_t c = 0;
+    for (uint32_t w = lane; w < nwords; w += 64u) {
+        uint32_t v = rowmajor[(size_t)row * ldw + w];
+        const uint32_t rem = n_hap - w * 32u;
+        if (rem < 32u) v &= (1u << rem) - 1u;   // pad bits must be zero
+        c += __builtin_popcount(v);
+        tiled[(((size_t)slab * nchunks + (w >> 2)) * kSlab + rin) * 4u + (w & 3u)] = v;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+    if (lane == 0 && cnt) cnt[row] = c;
+}
+
+// fa = a/n, fr = r/n (calc_ld.py:41-44: one correctly rounded division each), q = fa*fr.
+__global__ void snp_stats_kernel(const uint32_t *__restrict__ acnt, const uint32_t *__restrict__ rcnt,
+                                 uint32_t n_snps, uint32_t n_pad, double n, double *__restrict__ fa,
+                                 double *__restrict__ fr, double *__restrict__ q)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pad) return;
+    double a = 0.0, r = 0.0;
+    if (i < n_snps) {
+        a = (double)acnt[i] / n;
+        r = (double)rcnt[i] / n;
+    }
+    fa[i] = a;
+    fr[i] = r;
+    q[i] = a * r;
+}
+
+// round(a/n, 4) per SNP: var_i_alt_freq of calc_ld.py:96-97 and the query alt_freq of ld_area.py:188-189
+__global__ void alt_freq4_kernel(const uint32_t *__restrict__ acnt, uint32_t n_snps, double n, double *__restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_snps) out[i] = round4_k((double)acnt[i] / n) / 1e4;
+}
+
+}  // namespace ldx
+
+using namespace ldx;
+
+extern "C" int ldx_pack_codes_dev(const int8_t *codes, uint32_t n_snps, uint32_t n_hap, size_t ld_codes,
+                                  void *alt, void *ref, uint32_t *acnt, uint32_t *rcnt, void *stream)
+{
+    LDX_REQUIRE(codes && alt && acnt, "codes, alt and acnt must be non-null");
+    LDX_REQUIRE((ref == nullptr) == (rcnt == nullptr), "ref and rcnt must be given together");
+    LDX_REQUIRE(n_snps > 0 && n_hap > 0 && ld_codes >= n_hap, "bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t bytes = ldx_plane_bytes(n_snps, n_hap);
+    const uint32_t npad = ldx_padded_snps(n_snps);
+    LDX_HIP(hipMemsetAsync(alt, 0, bytes, s));
+    LDX_HIP(hipMemsetAsync(acnt, 0, npad * sizeof(uint32_t), s));
+    if (ref) {
+        LDX_HIP(hipMemsetAsync(ref, 0, bytes, s));
+        LDX_HIP(hipMemsetAsync(rcnt, 0, npad * sizeof(uint32_t), s));
+    }
+    pack_codes_kernel<<<(n_snps + 3u) / 4u, 256, 0, s>>>(codes, n_snps, n_hap, ld_codes, (uint16_t *)alt,
+                                                        (uint16_t *)ref, acnt, rcnt, n_chunks(n_hap));
+    LDX_HIP(hipGetLastError());
+    return LDX_OK;
+}
+
+extern "C" int ldx_tile_plane_dev(const uint32_t *rowmajor, uint32_t n_snps, uint32_t n_hap, size_t ld_words,
+                                  void *tiled, uint32_t *cnt, void *stream)
+{
+    LDX_REQUIRE(rowmajor && tiled, "null pointer");
+    LDX_REQUIRE(n_snps > 0 && n_hap > 0 && ld_words * 32u >= n_hap, "bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    LDX_HIP(hipMemsetAsync(tiled, 0, ldx_plane_bytes(n_snps, n_hap), s));
+    if (cnt) LDX_HIP(hipMemsetAsync(cnt, 0, ldx_padded_snps(n_snps) * sizeof(uint32_t), s));
+    tile_plane_kernel<<<(n_snps + 3u) / 4u, 256, 0, s>>>(rowmajor, n_snps, n_hap, ld_words, (uint32_t *)tiled, cnt,
+                                                        n_chunks(n_hap));
+    LDX_HIP(hipGetLastError());
+    return LDX_OK;
+}
+
+extern "C" int ldx_snp_stats_dev(const uint32_t *acnt, const uint32_t *rcnt, uint32_t n_snps, uint32_t n_hap,
+                                 double *fa, double *fr, double *q, void *stream)
+{
+    LDX_REQUIRE(acnt && rcnt && fa && fr && q, "null pointer");
+    LDX_REQUIRE(n_snps > 0 && n_hap > 0, "bad shape");
+    const uint32_t npad = ldx_padded_snps(n_snps);
+    snp_stats_kernel<<<(npad + 255u) / 256u, 256, 0, (hipStream_t)stream>>>(acnt, rcnt, n_snps, npad, (double)n_hap,
+                                                                           fa, fr, q);
+    LDX_HIP(hipGetLastError());
+    return LDX_OK;
+}
+
+extern "C" int ldx_alt_freq4_dev(const uint32_t *acnt, uint32_t n_snps, uint32_t n_hap, double *freq4, void *stream)
+{
+    LDX_REQUIRE(acnt && freq4, "null pointer");
+    LDX_REQUIRE(n_snps > 0 && n_hap > 0, "bad shape");
+    alt_freq4_kernel<<<(n_snps + 255u) / 256u, 256, 0, (hipStream_t)stream>>>(acnt, n_snps, (double)n_hap, freq4);
+    LDX_HIP(hipGetLastError());
+    return LDX_OK;
+}

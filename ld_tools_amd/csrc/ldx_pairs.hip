@@ -1,0 +1,325 @@
+// All-pairs alt/alt haplotype counts (calc_ld.py:32) fused with the D / D' / r^2 epilogue
+// (calc_ld.py:33-97), for the ld_triangle pair loop (ld_triangle.py:133-230).
+//
+// Execution model (gfx950, wave64)
+//   * A workgroup keeps ONE j-tile -- 128 SNP rows x all haplotype chunks, <= 160 KiB -- resident in
+//     LDS, copied linearly from the tiled plane (the HBM image is already the LDS image).
+//   * A wavefront processes "units": 8 consecutive i-rows against the 128 j-rows of the tile.  The
+//     i-rows are wave-uniform, so their words are fetched with scalar loads and sit in SGPRs; each
+//     lane owns j-rows `lane` and `lane + 64` and reads them with conflict-free ds_read_b128.  The
+//     inner loop is nothing but v_and_b32 (SGPR x VGPR) + v_bcnt_u32_b32 (accumulating).
+//   * 16 pair counts per lane stay in registers and go straight through the fp64 epilogue; one
+//     8-byte store per pair, 512 contiguous bytes per wave store.
+//   * Workgroups (one per CU, 16 waves) are persistent over a contiguous, equal share of the unit list
+//     (t-major), so a tile is staged once per workgroup per tile; units are dealt round-robin to the
+//     waves (all units cost the same, so a static deal is as good as a queue and needs no LDS word:
+//     at 5008 haplotypes the tile alone is 80 KiB).
+#include "ldx_common.h"
+#include "ldx_tile.h"
+
+namespace ldx {
+
+__device__ inline uint32_t find_tile(uint64_t u, uint64_t G, uint32_t T)
+{
+    uint32_t lo = 0, hi = T;   // largest t with tile_base(t) <= u
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) / 2;
+        if (tile_base(mid, G) <= u) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+template <bool kRaw, bool kN11>
+__global__ void __launch_bounds__(kThreads)
+triangle_kernel(const uint4 *__restrict__ alt, const double *__restrict__ fa, const double *__restrict__ fr,
+                const double *__restrict__ q, uint32_t n_snps, uint32_t n_slabs, uint32_t nchunks, double n,
+                uint64_t u_begin, uint64_t u_end, ldx_ld32 *__restrict__ out, ldx_ld64 *__restrict__ raw,
+                uint32_t *__restrict__ n11)
+{
+    extern __shared__ uint4 lds[];
+    uint4 *jt = lds;
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t G = (uint64_t)n_slabs * kGroupsPerSlab;
+    const uint64_t total = u_end - u_begin;
+    const uint64_t b0 = u_begin + total * blockIdx.x / gridDim.x;
+    const uint64_t b1 = u_begin + total * (blockIdx.x + 1) / gridDim.x;
+    if (b0 >= b1) return;   // block-uniform
+
+    uint32_t t = find_tile(b0, G, n_slabs);
+    uint64_t u = b0;
+    while (u < b1) {   // block-uniform trip count: every wave reaches every barrier
+        const uint64_t tb = tile_base(t, G);
+        const uint64_t te = tile_base(t + 1u, G);
+        const uint64_t seg_end = b1 < te ? b1 : te;
+        const uint32_t seg_len = (uint32_t)(seg_end - u);
+        __syncthreads();   // everyone is done with the previous tile
+        stage_tile(jt, alt + (size_t)t * nchunks * kSlab, nchunks * kSlab);
+        const uint32_t j0 = t * kSlab + lane, j1 = j0 + 64u;
+        const double fa2[2] = {fa[j0], fa[j1]};
+        const double fr2[2] = {fr[j0], fr[j1]};
+        __syncthreads();
+
+        for (uint32_t k = wave; k < seg_len; k += kWaves) {
+            const uint64_t uu = u + k;
+            const uint32_t g = (uint32_t)(uu - tb) + t * kGroupsPerSlab;   // i-group
+            const uint32_t row0 = g * kGroup;
+            const uint4 *ai = alt + ((size_t)(row0 / kSlab) * nchunks) * kSlab + (row0 % kSlab);
+            Acc acc;
+            count_unit(ai, jt, nchunks, lane, acc);
+
+            const size_t obase = (size_t)(uu - u_begin) * LDX_UNIT_PAIRS;
+#pragma unroll
+            for (int r = 0; r < (int)kGroup; ++r) {
+                const uint32_t i = row0 + r;
+                const double fa1 = fa[i], fr1 = fr[i], q1 = q[i];   // wave-uniform -> scalar loads
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const uint32_t j = jj ? j1 : j0;
+                    const bool valid = (i > j) && (i < n_snps);   // ld_triangle.py:149-150
+                    const size_t o = obase + (size_t)r * kSlab + jj * 64u + lane;
+                    ldx_ld32 res = {0.0f, 0.0f};
+                    ldx_ld64 rw = {0.0, 0.0};
+                    if (valid) {
+                        const double f11 = (double)acc.v[r][jj] / n;   // calc_ld.py:33
+                        const LdRaw lr = ld_epilogue(f11, fa1, fr1, q1, fa2[jj], fr2[jj]);
+                        res = round_pair(lr);
+                        rw.r_square = lr.rsq;
+                        rw.d_prime = lr.dprime;
+                    }
+                    out[o] = res;
+                    if (kRaw) raw[o] = rw;
+                    if (kN11) n11[o] = valid ? acc.v[r][jj] : 0u;
+                }
+            }
+        }
+        u = seg_end;
+        ++t;
+    }
+}
+
+// ---- rectangular n11 block: panel I rows x panel J rows, dense output (the bit-exact contract) ----
+__global__ void __launch_bounds__(kThreads)
+pair_counts_kernel(const uint4 *__restrict__ alt_i, const uint4 *__restrict__ alt_j, uint32_t n_i, uint32_t n_j,
+                   uint32_t nchunks, uint32_t *__restrict__ n11, size_t ld)
+{
+    extern __shared__ uint4 lds[];
+    uint4 *jt = lds;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t t = blockIdx.x;                          // j-tile
+    const uint32_t groups_i = (n_i + kGroup - 1) / kGroup;  // the I plane is padded to whole slabs
+    stage_tile(jt, alt_j + (size_t)t * nchunks * kSlab, nchunks * kSlab);
+    __syncthreads();
+    for (uint32_t g = blockIdx.y * kWaves + wave; g < groups_i; g += gridDim.y * kWaves) {
+        const uint32_t row0 = g * kGroup;
+        const uint4 *ai = alt_i + ((size_t)(row0 / kSlab) * nchunks) * kSlab + (row0 % kSlab);
+        Acc acc;
+        count_unit(ai, jt, nchunks, lane, acc);
+#pragma unroll
+        for (int r = 0; r < (int)kGroup; ++r) {
+            const uint32_t i = row0 + r;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const uint32_t j = t * kSlab + jj * 64u + lane;
+                if (i < n_i && j < n_j) n11[(size_t)i * ld + j] = acc.v[r][jj];
+            }
+        }
+    }
+}
+
+// ---- the epilogue alone, one element per thread ----
+__global__ void ld_from_counts_kernel(double n, size_t m, const uint32_t *__restrict__ n11,
+                                      const uint32_t *__restrict__ a1, const uint32_t *__restrict__ r1,
+                                      const uint32_t *__restrict__ a2, const uint32_t *__restrict__ r2,
+                                      ldx_ld64 *raw, ldx_ld32 *rounded, uint8_t *flags)
+{
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= m) return;
+    const double fa1 = (double)a1[k] / n, fr1 = (double)r1[k] / n;
+    const double fa2 = (double)a2[k] / n, fr2 = (double)r2[k] / n;
+    const LdRaw lr = ld_epilogue((double)n11[k] / n, fa1, fr1, fa1 * fr1, fa2, fr2);
+    if (raw) raw[k] = ldx_ld64{lr.rsq, lr.dprime};
+    if (rounded) rounded[k] = round_pair(lr);
+    if (flags) flags[k] = (uint8_t)lr.flags;
+}
+
+// ---- strips -> dense ld_two_dim (ld_triangle.py:114,223-230) ----
+__global__ void triangle_dense_kernel(const ldx_ld32 *__restrict__ strips, uint32_t n_snps, uint32_t n_slabs,
+                                      int measure, int has_thres, double k_thres, uint32_t row_begin,
+                                      uint32_t row_end, float *__restrict__ dense, size_t ld)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = row_begin + blockIdx.y;
+    if (j >= n_snps || i >= row_end) return;
+    float v = -0.0f;   // the template's int 0 (ld_triangle.py:114)
+    if (i > j) {
+        const uint64_t G = (uint64_t)n_slabs * kGroupsPerSlab;
+        const uint32_t t = j / kSlab, g = i / kGroup;
+        const uint64_t u = tile_base(t, G) + (g - t * kGroupsPerSlab);
+        const ldx_ld32 c = strips[u * LDX_UNIT_PAIRS + (i % kGroup) * kSlab + (j % kSlab)];
+        v = measure == LDX_MEASURE_RSQ ? c.r_square : c.d_prime;
+        // ld_triangle.py:223-225 compares the rounded value k/10^4 with the threshold; k_thres is the
+        // smallest k whose k/10^4 is not below it.  Sub-threshold cells keep the template's int 0.
+        if (has_thres && __builtin_rint((double)v * 1e4) < k_thres) v = -0.0f;
+    }
+    dense[(size_t)(i - row_begin) * ld + j] = v;
+}
+
+// ---- peak-rate probe for the inner loop's instruction pair ----
+// 16 accumulators x 4 words per round = 64 v_and_b32 (SGPR x VGPR) + 64 accumulating v_bcnt_u32_b32 per
+// lane and round, no memory traffic: what the VALU sustains for exactly the inner loop's two opcodes.
+__global__ void __launch_bounds__(1024) probe_andpop_kernel(uint32_t *__restrict__ sink, uint32_t iters)
+{
+    uint32_t acc[16];
+    uint32_t b[4];
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) b[k] = tid * 2654435761u + k * 40503u;
+    uint32_t a = __builtin_amdgcn_readfirstlane(blockIdx.x * 747796405u + 2891336453u);
+    for (uint32_t it = 0; it < iters; ++it) {
+        uint32_t s[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s[k] = a ^ (0x9E3779B9u * (k + 1));   // SALU
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) popacc(acc[k], s[k] & b[w]);
+        }
+        a = a * 1664525u + 1013904223u;
+    }
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += acc[k];
+    sink[tid] = s;
+}
+
+}  // namespace ldx
+
+using namespace ldx;
+
+static size_t tile_lds_bytes(uint32_t nchunks) { return (size_t)nchunks * kSlab * 16u; }
+
+static int ensure_lds(const void *kernel, size_t bytes)
+{
+    // > 64 KiB of dynamic LDS needs the opt-in attribute
+    LDX_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return LDX_OK;
+}
+
+static int num_cus()
+{
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+        prop.multiProcessorCount > 0)
+        return prop.multiProcessorCount;
+    return 256;
+}
+
+template <bool kRaw, bool kN11>
+static int launch_triangle(const void *alt, const double *fa, const double *fr, const double *q, uint32_t n_snps,
+                           uint32_t n_hap, uint64_t unit_begin, uint64_t unit_end, ldx_ld32 *out, ldx_ld64 *out_raw,
+                           uint32_t *out_n11, hipStream_t s)
+{
+    const uint32_t nch = ldx::n_chunks(n_hap);
+    const size_t lds = tile_lds_bytes(nch);
+    int rc = ensure_lds((const void *)triangle_kernel<kRaw, kN11>, lds);
+    if (rc) return rc;
+    const uint64_t total = unit_end - unit_begin;
+    uint64_t grid = (uint64_t)num_cus();   // persistent: one 16-wave workgroup per CU
+    const uint64_t max_grid = (total + kWaves - 1) / kWaves;   // at least one unit per wave
+    if (grid > max_grid) grid = max_grid;
+    triangle_kernel<kRaw, kN11><<<(uint32_t)grid, kThreads, lds, s>>>(
+        (const uint4 *)alt, fa, fr, q, n_snps, ldx::n_slabs(n_snps), nch, (double)n_hap, unit_begin, unit_end, out,
+        out_raw, out_n11);
+    LDX_HIP(hipGetLastError());
+    return LDX_OK;
+}
+
+extern "C" int ldx_triangle_dev(const void *alt, const double *fa, const double *fr, const double *q,
+                                uint32_t n_snps, uint32_t n_hap, uint64_t unit_begin, uint64_t unit_end,
+                                ldx_ld32 *out, ldx_ld64 *out_raw, uint32_t *out_n11, void *stream)
+{
+    LDX_REQUIRE(alt && fa && fr && q && out, "null pointer");
+    LDX_REQUIRE(n_snps >= 1 && n_hap >= 1, "bad shape");
+    if (n_hap > LDX_MAX_HAPS) {
+        set_error("ldx_triangle_dev: n_hap %u > LDX_MAX_HAPS %u", n_hap, LDX_MAX_HAPS);
+        return LDX_E_UNSUPPORTED;
+    }
+    const uint64_t U = ldx_triangle_units(n_snps);
+    if (unit_end > U) unit_end = U;
+    if (unit_begin >= unit_end) return LDX_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (out_raw && out_n11)
+        return launch_triangle<true, true>(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end, out, out_raw, out_n11, s);
+    if (out_raw)
+        return launch_triangle<true, false>(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end, out, out_raw, out_n11, s);
+    if (out_n11)
+        return launch_triangle<false, true>(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end, out, out_raw, out_n11, s);
+    return launch_triangle<false, false>(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end, out, out_raw, out_n11, s);
+}
+
+extern "C" int ldx_pair_counts_dev(const void *alt_i, uint32_t n_i, const void *alt_j, uint32_t n_j,
+                                   uint32_t n_hap, uint32_t *n11, size_t ld, void *stream)
+{
+    LDX_REQUIRE(alt_i && alt_j && n11, "null pointer");
+    LDX_REQUIRE(n_i >= 1 && n_j >= 1 && n_hap >= 1 && ld >= n_j, "bad shape");
+    if (n_hap > LDX_MAX_HAPS) {
+        set_error("ldx_pair_counts_dev: n_hap %u > LDX_MAX_HAPS %u", n_hap, LDX_MAX_HAPS);
+        return LDX_E_UNSUPPORTED;
+    }
+    const uint32_t nch = ldx::n_chunks(n_hap);
+    const size_t lds = tile_lds_bytes(nch);
+    int rc = ensure_lds((const void *)pair_counts_kernel, lds);
+    if (rc) return rc;
+    const uint32_t tiles_j = ldx::n_slabs(n_j);
+    const uint32_t groups_i = (n_i + kGroup - 1) / kGroup;
+    uint32_t gy = (groups_i + kWaves - 1) / kWaves;
+    const uint32_t want = (uint32_t)(num_cus() + tiles_j - 1) / tiles_j;   // ~1 workgroup per CU in total
+    if (gy > want) gy = want;
+    if (gy < 1) gy = 1;
+    pair_counts_kernel<<<dim3(tiles_j, gy), kThreads, lds, (hipStream_t)stream>>>(
+        (const uint4 *)alt_i, (const uint4 *)alt_j, n_i, n_j, nch, n11, ld);
+    LDX_HIP(hipGetLastError());
+    return LDX_OK;
+}
+
+extern "C" int ldx_ld_from_counts_dev(uint32_t n, size_t m, const uint32_t *n11, const uint32_t *a1,
+                                      const uint32_t *r1, const uint32_t *a2, const uint32_t *r2,
+                                      ldx_ld64 *raw, ldx_ld32 *rounded, uint8_t *flags, void *stream)
+{
+    LDX_REQUIRE(n11 && a1 && r1 && a2 && r2, "null pointer");
+    LDX_REQUIRE(n >= 1, "n must be positive (the reference raises ZeroDivisionError, calc_ld.py:33)");
+    if (m == 0) return LDX_OK;
+    ld_from_counts_kernel<<<(uint32_t)((m + 255) / 256), 256, 0, (hipStream_t)stream>>>((double)n, m, n11, a1, r1, a2,
+                                                                                      r2, raw, rounded, flags);
+    LDX_HIP(hipGetLastError());
+    return LDX_OK;
+}
+
+extern "C" int ldx_triangle_dense_dev(const ldx_ld32 *strips, uint32_t n_snps, int measure, int has_thres,
+                                      double thres, uint32_t row_begin, uint32_t row_end, float *dense, size_t ld,
+                                      void *stream)
+{
+    LDX_REQUIRE(strips && dense, "null pointer");
+    LDX_REQUIRE(row_begin <= row_end && row_end <= n_snps && ld >= n_snps, "bad shape");
+    LDX_REQUIRE(measure == LDX_MEASURE_RSQ || measure == LDX_MEASURE_DPRIME, "bad measure");
+    if (row_begin == row_end) return LDX_OK;
+    triangle_dense_kernel<<<dim3((n_snps + 255u) / 256u, row_end - row_begin), 256, 0, (hipStream_t)stream>>>(
+        strips, n_snps, ldx::n_slabs(n_snps), measure, has_thres, has_thres ? thres_to_k(thres) : 0.0, row_begin,
+        row_end, dense, ld);
+    LDX_HIP(hipGetLastError());
+    return LDX_OK;
+}
+
+extern "C" int ldx_probe_andpop_dev(uint32_t *sink, uint32_t blocks, uint32_t threads, uint32_t iters, void *stream)
+{
+    LDX_REQUIRE(sink && blocks >= 1 && threads >= 64 && threads <= 1024 && threads % 64 == 0, "bad argument");
+    probe_andpop_kernel<<<blocks, threads, 0, (hipStream_t)stream>>>(sink, iters);
+    LDX_HIP(hipGetLastError());
+    return LDX_OK;
+}

@@ -1,0 +1,201 @@
+"""Batched LD operators over a PackedPanel -- the host-side mirror of the reference's pair loops.
+
+    ld_triangle(panel)                      <- ld_triangle.py:133-230  (all row > col pairs)
+    ld_area(panel, positions, queries, ...) <- ld_area.py:152-276      (windowed scan, thresholded hits)
+    pair_counts(panel_i, panel_j)           <- calc_ld.py:32           (bit-exact n11 block)
+    ld_from_counts(n, n11, a1, r1, a2, r2)  <- calc_ld.py:33-97        (the epilogue alone)
+
+Every function enqueues HIP kernels of libldx.so on torch's current stream and returns device
+tensors; nothing here computes LD on the host.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import MEASURES, UNIT_PAIRS, check, lib
+from .panel import PackedPanel, _ptr, _stream_ptr
+
+
+# --------------------------------------------------------------------------- triangle
+@dataclass
+class TriangleResult:
+    """Strip-packed lower triangle of one panel (layout: include/ldx.h, "Triangle work units")."""
+
+    n_snps: int
+    unit_begin: int
+    unit_end: int
+    ld32: torch.Tensor                       # float32 [(units)*1024, 2]  (r_square, d_prime) rounded to 4 dp
+    raw: Optional[torch.Tensor] = None       # float64 [(units)*1024, 2]  unrounded
+    n11: Optional[torch.Tensor] = None       # int32   [(units)*1024]     alt/alt haplotype counts
+
+    def cell_index(self, rows, cols) -> np.ndarray:
+        """Flat element index (relative to this shard) of cells (row > col)."""
+        rows = np.asarray(rows, dtype=np.int64)
+        cols = np.asarray(cols, dtype=np.int64)
+        if np.any(rows <= cols):
+            raise ValueError("cell_index needs row > col")
+        npad = lib.ldx_padded_snps(self.n_snps)
+        G = npad // 8
+        t = cols // 128
+        g = rows // 8
+        u = t * G - 8 * t * (t - 1) + (g - 16 * t)
+        return (u - self.unit_begin) * UNIT_PAIRS + (rows % 8) * 128 + (cols % 128)
+
+    def dense(self, measure: str = "r_square", thres: Optional[float] = None,
+              rows: Optional[Tuple[int, int]] = None) -> torch.Tensor:
+        """ld_two_dim of ld_triangle.py:114,223-230 as float32 [rows][n_snps] on the device.
+
+        Cells the reference leaves at the template's int 0 (row <= col, or rounded measure below
+        ``thres``) hold -0.0; a computed int 0 (monomorphic variant) is -0.0 too, a float 0.0 is +0.0.
+        Needs the full triangle (unit_begin == 0 and all units present).
+        """
+        if self.unit_begin != 0 or self.unit_end != lib.ldx_triangle_units(self.n_snps):
+            raise _lib.LdxError("dense() needs an unsharded TriangleResult")
+        r0, r1 = rows if rows is not None else (0, self.n_snps)
+        out = torch.empty((r1 - r0, self.n_snps), dtype=torch.float32, device=self.ld32.device)
+        check(lib.ldx_triangle_dense_dev(self.ld32.data_ptr(), self.n_snps, MEASURES[measure],
+                                         0 if thres is None else 1, 0.0 if thres is None else float(thres),
+                                         r0, r1, out.data_ptr(), self.n_snps, _stream_ptr()),
+              "ldx_triangle_dense_dev")
+        return out
+
+
+def ld_triangle(panel: PackedPanel, unit_range: Optional[Tuple[int, int]] = None, want_raw: bool = False,
+                want_n11: bool = False, out: Optional[TriangleResult] = None) -> TriangleResult:
+    """All row > col pairs of the panel: var_1 = row, var_2 = col (ld_triangle.py:193-194).
+
+    ``unit_range`` restricts the work to a contiguous slice of the unit list (multi-GPU sharding);
+    ``out`` re-uses the buffers of a previous result of the same shape (benchmark loops).
+    """
+    total = panel.n_units
+    u0, u1 = (0, total) if unit_range is None else unit_range
+    u0, u1 = max(0, u0), min(total, u1)
+    cells = max(0, u1 - u0) * UNIT_PAIRS
+    dev = panel.device
+    if out is None:
+        out = TriangleResult(panel.n_snps, u0, u1, torch.empty((cells, 2), dtype=torch.float32, device=dev),
+                             torch.empty((cells, 2), dtype=torch.float64, device=dev) if want_raw else None,
+                             torch.empty(cells, dtype=torch.int32, device=dev) if want_n11 else None)
+    elif (out.n_snps, out.unit_begin, out.unit_end) != (panel.n_snps, u0, u1):
+        raise _lib.LdxError("ld_triangle: `out` has a different shape")
+    if cells:
+        check(lib.ldx_triangle_dev(panel.alt.data_ptr(), panel.fa.data_ptr(), panel.fr.data_ptr(),
+                                   panel.q.data_ptr(), panel.n_snps, panel.n_hap, u0, u1, out.ld32.data_ptr(),
+                                   _ptr(out.raw), _ptr(out.n11), _stream_ptr()), "ldx_triangle_dev")
+    return out
+
+
+# --------------------------------------------------------------------------- n11 block / epilogue
+def pair_counts(panel_i: PackedPanel, panel_j: Optional[PackedPanel] = None) -> torch.Tensor:
+    """n11[i][j] = #haplotypes with code 1 at SNP i of panel_i and SNP j of panel_j (calc_ld.py:32)."""
+    pj = panel_j or panel_i
+    if pj.n_hap != panel_i.n_hap:
+        raise _lib.LdxError("pair_counts: panels differ in haplotype count")
+    out = torch.empty((panel_i.n_snps, pj.n_snps), dtype=torch.int32, device=panel_i.device)
+    check(lib.ldx_pair_counts_dev(panel_i.alt.data_ptr(), panel_i.n_snps, pj.alt.data_ptr(), pj.n_snps,
+                                  panel_i.n_hap, out.data_ptr(), pj.n_snps, _stream_ptr()),
+          "ldx_pair_counts_dev")
+    return out
+
+
+def ld_from_counts(n: int, n11, a1, r1, a2, r2, device: Optional[torch.device] = None):
+    """The epilogue alone (calc_ld.py:33-97) on arrays of counts.
+
+    Returns (raw float64 [m,2], rounded float32 [m,2], flags uint8 [m]) as device tensors.
+    """
+    dev = device or torch.device("cuda", torch.cuda.current_device())
+    def up(x):
+        t = torch.as_tensor(np.ascontiguousarray(np.asarray(x, dtype=np.uint32)).view(np.int32))
+        return t.to(dev)
+    t11, ta1, tr1, ta2, tr2 = (up(x) for x in (n11, a1, r1, a2, r2))
+    m = t11.numel()
+    raw = torch.empty((m, 2), dtype=torch.float64, device=dev)
+    rnd = torch.empty((m, 2), dtype=torch.float32, device=dev)
+    flags = torch.empty(m, dtype=torch.uint8, device=dev)
+    check(lib.ldx_ld_from_counts_dev(int(n), m, t11.data_ptr(), ta1.data_ptr(), tr1.data_ptr(), ta2.data_ptr(),
+                                     tr2.data_ptr(), raw.data_ptr(), rnd.data_ptr(), flags.data_ptr(),
+                                     _stream_ptr()), "ldx_ld_from_counts_dev")
+    return raw, rnd, flags
+
+
+# --------------------------------------------------------------------------- area
+@dataclass
+class AreaHits:
+    """Thresholded hits of a windowed scan, sorted by (query row, opposing row) = VCF order."""
+
+    query: torch.Tensor       # int64 [n]  panel row of var_1 (the query)
+    oppos: torch.Tensor       # int64 [n]  panel row of var_2 (the opposing variant)
+    ld32: torch.Tensor        # float32 [n, 2]  rounded (r_square, d_prime), -0.0 = int 0
+    n_pairs: int              # (query, opposing) pairs inside the windows that were evaluated
+
+    def __len__(self) -> int:
+        return int(self.query.numel())
+
+
+def ld_area(panel: PackedPanel, positions, queries: Optional[Sequence[int]] = None, flank: int = 100000,
+            measure: str = "r_square", thres: float = 0.8, hit_capacity: Optional[int] = None) -> AreaHits:
+    """Windowed scan of ld_area.py:152-276 over the panel.
+
+    positions: ascending 1-based coordinates of the panel's SNPs (VCF order).  queries: panel
+    row indices of the query variants (default: every SNP).  For each query q the opposing
+    variants are o != q with max(0, pos_q - flank) < pos_o <= pos_q + flank (pysam's fetch,
+    ld_area.py:174-177,215-217); var_1 = query, var_2 = opposing; kept when the rounded
+    ``measure`` >= thres (ld_area.py:248).
+    """
+    dev = panel.device
+    pos = torch.as_tensor(np.ascontiguousarray(np.asarray(positions, dtype=np.int64))) \
+        if not isinstance(positions, torch.Tensor) else positions
+    pos = pos.to(dev, dtype=torch.int64).contiguous()
+    if pos.numel() != panel.n_snps:
+        raise _lib.LdxError("positions must have one entry per SNP")
+    if queries is None:
+        q = torch.arange(panel.n_snps, dtype=torch.int32, device=dev)
+    else:
+        qn = np.sort(np.asarray(queries, dtype=np.int64))   # the kernel wants ascending rows
+        if qn.size == 0:
+            e = torch.empty(0, dtype=torch.int64, device=dev)
+            return AreaHits(e, e, torch.empty((0, 2), dtype=torch.float32, device=dev), 0)
+        if qn[0] < 0 or qn[-1] >= panel.n_snps:
+            raise _lib.LdxError("query row out of range")
+        q = torch.as_tensor(qn.astype(np.int32)).to(dev)
+    nq = int(q.numel())
+    ws_bytes = lib.ldx_area_workspace_bytes(panel.n_snps, panel.n_hap, nq)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    n_hits = torch.zeros(1, dtype=torch.int64, device=dev)
+    cap = int(hit_capacity) if hit_capacity is not None else max(1 << 16, 64 * nq)
+    while True:
+        hits = torch.empty((cap, 4), dtype=torch.int32, device=dev)   # ldx_hit = {u32, u32, f32, f32}
+        check(lib.ldx_area_dev(panel.alt.data_ptr(), panel.fa.data_ptr(), panel.fr.data_ptr(), panel.q.data_ptr(),
+                               panel.n_snps, panel.n_hap, pos.data_ptr(), q.data_ptr(), nq, int(flank),
+                               MEASURES[measure], float(thres), hits.data_ptr(), cap, n_hits.data_ptr(),
+                               ws.data_ptr(), ws_bytes, _stream_ptr()), "ldx_area_dev")
+        reserved = int(n_hits.item())
+        if reserved <= cap:
+            break
+        cap = reserved + 4096            # the count is exact for a re-run: one retry suffices
+    hits = hits[:reserved]
+    valid = hits[:, 0] != -1             # UINT32_MAX marks an unused slot of a wave's batch
+    hits = hits[valid]
+    qrow = hits[:, 0].to(torch.int64) & 0xFFFFFFFF
+    orow = hits[:, 1].to(torch.int64) & 0xFFFFFFFF
+    order = torch.argsort(qrow * panel.n_snps + orow)
+    ld32 = hits[:, 2:4].contiguous().view(torch.float32)[order]
+    # pairs evaluated = sum over queries of window population (bookkeeping for the bench, on device)
+    qpos = pos[q.to(torch.int64)]
+    lo = torch.searchsorted(pos, torch.clamp(qpos - flank, min=0), right=True)
+    hi = torch.searchsorted(pos, qpos + flank, right=True)
+    self_in = torch.clamp(qpos - flank, min=0) < qpos      # the query lies in its own window unless flank == 0
+    n_pairs = int((hi - lo).sum().item()) - int(self_in.sum().item())
+    return AreaHits(qrow[order], orow[order], ld32, n_pairs)
+
+
+# --------------------------------------------------------------------------- instrumentation
+def probe_andpop(blocks: int, threads: int, iters: int) -> torch.Tensor:
+    sink = torch.empty(blocks * threads, dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+    check(lib.ldx_probe_andpop_dev(sink.data_ptr(), blocks, threads, iters, _stream_ptr()), "ldx_probe_andpop_dev")
+    return sink
