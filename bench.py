@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""Benchmark of the pairwise-LD hot path on MI355X: SNP-pairs/s producing r^2 + D'.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--snps S] [--haps H]
+
+One "step" = one full pass of the hot path over one synthetic panel that is already resident in HBM
+as packed slab shards: (N > 1: all-gather of the shards over RCCL) -> ld_triangle kernel over this
+rank's share of the pair list -> 8 bytes per pair (float32 r^2, float32 D', 4-decimal) written to HBM.
+
+Workload (BASELINE.json): N = 1 -> configs[1], ld_triangle 10 000 SNPs x 5008 haplotypes.  N > 1 keeps
+the pairs per GPU constant (weak scaling): S = 10 000 * sqrt(N) SNPs rounded up to whole 128-row slabs,
+row-block shards packed per rank, exchanged by all-gather, unit list split evenly (ld_tools_amd/dist.py).
+--snps overrides S (e.g. --snps 100000 for configs[3]).
+
+Prints ONE JSON line on rank 0 (see the driver contract): whole-job pairs/s, ms per step, the roofline
+object of the dominant kernel (HIP events on the launch stream, live) and, at N = 1, the CPU baseline
+(the pure-Python restatement of the reference's list/zip/count algorithm, 1 core, bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_TOPS = 157.3 / 2                # ... 157.3 TFLOP/s fp32 vector = 78.65 T lane-instructions/s
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--snps", type=int, default=0, help="panel size (default: 10000 * sqrt(gpus))")
+    ap.add_argument("--haps", type=int, default=5008)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-snps", type=int, default=224)
+    return ap.parse_args()
+
+
+def cpu_baseline(codes_host, sample_snps):
+    """Time the oracle's pure-Python list/zip/count path (kind "port") on the first rows of the bench panel."""
+    from oracle import c_oracle
+    from oracle import ld_oracle as orc
+
+    rows = [r.tolist() for r in codes_host[:sample_snps]]
+    t0 = time.perf_counter()
+    pairs = 0
+    for i in range(len(rows)):
+        gi = rows[i]
+        for j in range(i):
+            orc.calc_ld_lists(gi, rows[j])
+            pairs += 1
+    dt = time.perf_counter() - t0
+    out = {"value": pairs / dt, "unit": "pairs/s", "cores": 1, "kind": "port",
+           "sample": f"all {pairs} row>col pairs of the first {len(rows)} SNPs of the bench panel "
+                     f"({codes_host.shape[1]} haplotypes), oracle/ld_oracle.py calc_ld_lists, {dt:.1f} s",
+           "cpu": _cpu_model(), "host_cores": os.cpu_count()}
+    # the C restatement (AND + popcount + fp64 mirror), one thread, as the stronger CPU comparator
+    n_c = min(codes_host.shape[0], 1536)
+    p = c_oracle.Panel(codes_host[:n_c])
+    t0 = time.perf_counter()
+    p.triangle(want=("rsq_rnd", "dp_rnd"))
+    dtc = time.perf_counter() - t0
+    out["native"] = {"value": (n_c * (n_c - 1) // 2) / dtc, "unit": "pairs/s", "cores": 1,
+                     "sample": f"{n_c}-SNP triangle, oracle/ld_oracle.c, {dtc:.1f} s"}
+    return out
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device; there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from ld_tools_amd import PackedPanel, dist as ldist, ld_triangle, ops, synth
+    from ld_tools_amd._lib import lib
+
+    n_hap = args.haps
+    if args.snps:
+        n_snps = args.snps
+    elif world == 1:
+        n_snps = 10000                                                   # BASELINE.json configs[1]
+    else:
+        n_snps = int(math.ceil(10000 * math.sqrt(world) / 128.0)) * 128  # constant pairs per GPU
+    n_pairs = n_snps * (n_snps - 1) // 2
+
+    # ---- setup (untimed): every rank ingests and packs its own row block ----
+    b, e = ldist.slab_partition(n_snps, world)[rank]
+    local = None
+    codes_local = None
+    if e > b:
+        codes_local = synth.synth_codes_device(e - b, n_hap, seed=synth.BENCH_SEED, snp_offset=b, device=dev)
+        local = PackedPanel.from_codes(codes_local)
+    u0, u1 = ldist.unit_partition(n_snps, world)[rank]
+    out = None
+    panel = local if world == 1 else None
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+
+    def step(k=None):
+        nonlocal out, panel
+        if world > 1:
+            panel = ldist.all_gather_panel(local, n_snps, n_hap)      # the exchange step (RCCL all-gather)
+        if k is not None:
+            ev0[k].record()
+        out = ld_triangle(panel, unit_range=(u0, u1), out=out)
+        if k is not None:
+            ev1[k].record()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    kern_ms = sum(a.elapsed_time(b_) for a, b_ in zip(ev0, ev1)) / args.steps
+    if world > 1:
+        t = torch.tensor([kern_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        kern_ms = float(t.item())
+
+    value = n_pairs * args.steps / dt
+    # ---- roofline of the dominant kernel (triangle_kernel), per launch, this rank's share ----
+    my_pairs = n_pairs / world
+    alg_bytes = 8.0 * my_pairs + lib.ldx_plane_bytes(n_snps, n_hap)     # 8 B/pair out + the ALT plane read once
+    lane_ops = 2.0 * math.ceil(n_hap / 32) * my_pairs                   # v_and_b32 + v_bcnt_u32_b32 per 32 haplotypes
+    achieved_gbs = alg_bytes / (kern_ms * 1e-3) / 1e9
+    traffic = None
+    tfile = ROOT / "profiles" / "traffic.json"
+    if tfile.exists():
+        try:
+            rec = json.loads(tfile.read_text())
+            if rec.get("workload") == f"ld_triangle {n_snps}x{n_hap}" and rec.get("gpus") == world:
+                traffic = rec.get("hbm_bytes_per_launch")
+        except (ValueError, OSError):
+            pass
+    line = {
+        "metric": "SNP-pairs/sec (r2+D')",
+        "value": value,
+        "unit": "pairs/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u32 popcount + f64 epilogue",
+        "data": "synthetic",
+        "config": {"workload": f"ld_triangle {n_snps}x{n_hap}", "n_snps": n_snps, "n_hap": n_hap,
+                   "pairs_per_step": n_pairs, "output": "8 B/pair (f32 r2, f32 D', rounded to 4 decimals) in HBM",
+                   "sharding": "none" if world == 1 else f"row-block shards, all-gather, unit list / {world}"},
+        "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                     "kernel": "triangle_kernel", "kernel_ms": kern_ms, "algorithmic_bytes": alg_bytes},
+        # the popcount path is VALU-bound, not HBM-bound (DESIGN.md "rooflines"): the governing ceiling
+        "roofline_valu": {"bound": "valu-int", "achieved": lane_ops / (kern_ms * 1e-3) / 1e12, "peak": VALU_PEAK_TOPS,
+                          "unit": "T lane-ops/s", "frac": lane_ops / (kern_ms * 1e-3) / 1e12 / VALU_PEAK_TOPS,
+                          "ops_per_pair": 2 * math.ceil(n_hap / 32)},
+    }
+    if rank == 0 and world == 1:
+        # peak of the inner loop's instruction pair, measured with the same opcodes and no memory traffic
+        iters = 4000
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        ops.probe_andpop(cus, 1024, 10)
+        torch.cuda.synchronize()
+        a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        ops.probe_andpop(cus, 1024, iters)
+        b_.record()
+        torch.cuda.synchronize()
+        probe = cus * 1024 * iters * 128 / (a.elapsed_time(b_) * 1e-3) / 1e12
+        line["roofline_valu"]["probe_and_bcnt_Tops"] = probe
+        line["roofline_valu"]["frac_of_probe"] = line["roofline_valu"]["achieved"] / probe
+        if not args.no_cpu_baseline:
+            need = max(args.cpu_sample_snps, 1536)
+            host = codes_local[:need].cpu().numpy()
+            line["cpu_baseline"] = cpu_baseline(host, args.cpu_sample_snps)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -46,16 +46,12 @@ def pair_counts_lists(g1, g2):
                       sequence (not the zipped prefix); any other code (None,
                       2, ...) is in n but in neither count.
     """
-    n = min(len(g1), len(g2))
-    n11 = 0
-    for x, y in zip(g1, g2):
-        if x == 1 and y == 1:
-            n11 += 1
-    a1 = sum(1 for x in g1 if x == 1)
-    r1 = sum(1 for x in g1 if x == 0)
-    a2 = sum(1 for y in g2 if y == 1)
-    r2 = sum(1 for y in g2 if y == 0)
-    return n, n11, a1, r1, a2, r2
+    g1 = g1 if isinstance(g1, (list, tuple)) else list(g1)
+    g2 = g2 if isinstance(g2, (list, tuple)) else list(g2)
+    pairs = list(zip(g1, g2))            # as many haplotypes as the shorter sequence
+    n = len(pairs)
+    n11 = pairs.count((1, 1))            # tuple equality: x == 1 and y == 1
+    return n, n11, g1.count(1), g1.count(0), g2.count(1), g2.count(0)
 
 
 def ld_raw_from_counts(n, n11, a1, r1, a2, r2):

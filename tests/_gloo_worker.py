@@ -1,0 +1,74 @@
+"""Worker for tests/test_dist_gloo.py: world_size-2 rehearsal of the sharded triangle on CPU (gloo).
+
+Each rank "packs" only its slab shard of a synthetic panel (numpy, in the tiled byte layout of
+include/ldx.h), the shards are all-gathered with ld_tools_amd.dist.gather_shards, every rank checks
+that the gathered plane equals the plane packed from the whole panel, then computes ITS unit range of
+the triangle with the C oracle and rank 0 checks that the union of the ranks' cells is the full
+triangle, each cell exactly once and equal to the single-process result.
+"""
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+from ld_tools_amd import dist as ldist  # noqa: E402
+from ld_tools_amd import synth  # noqa: E402
+from oracle import c_oracle  # noqa: E402
+
+
+def tiled_plane(codes: np.ndarray, n_hap: int) -> np.ndarray:
+    """uint8 tiled ALT plane of include/ldx.h for int8 codes [rows][n_hap] (rows padded to slabs)."""
+    rows = codes.shape[0]
+    slabs, chunks = (rows + 127) // 128, (n_hap + 127) // 128
+    bits = np.zeros((slabs * 128, chunks * 128), dtype=np.uint8)
+    bits[:rows, :n_hap] = codes == 1
+    by = np.packbits(bits, axis=1, bitorder="little").reshape(slabs, 128, chunks, 16)
+    return np.ascontiguousarray(by.transpose(0, 2, 1, 3)).reshape(-1)
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    for n_snps, n_hap in [(512, 200), (700, 137)]:       # equal and uneven slab shards
+        full_codes = synth.synth_codes_host(n_snps, n_hap, seed=3, miss=0.01)
+        parts = ldist.slab_partition(n_snps, world)
+        b, e = parts[rank]
+        mine = synth.synth_codes_host(e - b, n_hap, seed=3, miss=0.01, snp_offset=b)   # rank-local ingest
+        assert np.array_equal(mine, full_codes[b:e])
+        shard = torch.from_numpy(tiled_plane(mine, n_hap))
+        slab_bytes = ((n_hap + 127) // 128) * 128 * 16
+        sizes = [((pe - pb + 127) // 128) * slab_bytes for (pb, pe) in parts]
+        dst = torch.zeros(sum(sizes), dtype=torch.uint8)
+        ldist.gather_shards(dst, shard, sizes)
+        want = tiled_plane(full_codes, n_hap)
+        assert np.array_equal(dst.numpy(), want), "gathered plane differs from the whole-panel plane"
+
+        # sharded triangle: this rank's unit range, cells through the oracle
+        u0, u1 = ldist.unit_partition(n_snps, world)[rank]
+        rows, cols = ldist.unit_cells(n_snps, u0, u1)
+        p = c_oracle.Panel(full_codes)
+        n11 = np.array([int(p.pair_counts(r, r + 1, c, c + 1)[0, 0]) for r, c in zip(rows[::97], cols[::97])])
+        cover = torch.zeros((n_snps, n_snps), dtype=torch.int32)
+        cover[torch.from_numpy(rows), torch.from_numpy(cols)] = 1
+        dist.all_reduce(cover)
+        if rank == 0:
+            assert torch.equal(cover, torch.tril(torch.ones_like(cover), -1)), "cells not covered exactly once"
+        t = p.triangle(want=("n11",))["n11"]
+        assert np.array_equal(n11, t[rows[::97], cols[::97]])
+        pairs = torch.tensor([len(rows)], dtype=torch.int64)
+        dist.all_reduce(pairs)
+        assert int(pairs) == n_snps * (n_snps - 1) // 2
+    dist.barrier()
+    if rank == 0:
+        print("GLOO_OK")
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,136 @@
+"""CPU: the C-ABI library loads and exports what include/ldx.h declares; host-side logic.
+
+No kernel is launched here (there is no GPU in the build container).
+"""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def header_functions():
+    text = (ROOT / "include" / "ldx.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ldx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from ld_tools_amd import _lib
+
+    names = header_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(_lib.lib, n), f"{n} declared in ldx.h but not exported by libldx.so"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature in ld_tools_amd/_lib.py"
+    assert set(_lib.SIGNATURES) == set(names)
+    assert _lib.version() == 100
+
+
+def test_no_torch_or_python_dependency_in_library():
+    """The boundary is plain C: the shared object must not link torch / libpython."""
+    import subprocess
+
+    from ld_tools_amd import _lib
+
+    out = subprocess.run(["ldd", str(_lib.LIB_PATH)], capture_output=True, text=True).stdout
+    assert "libamdhip64" in out
+    assert "torch" not in out and "libpython" not in out
+
+
+def test_geometry_helpers():
+    from ld_tools_amd import _lib, dist
+
+    L = _lib.lib
+    for n in (1, 2, 127, 128, 129, 1000, 10000, 100000):
+        T = (n + 127) // 128
+        assert L.ldx_n_slabs(n) == T and L.ldx_padded_snps(n) == T * 128
+        assert L.ldx_triangle_units(n) == dist.triangle_units(n)
+        # every valid pair maps into the unit range, and tile bases are increasing
+        assert L.ldx_triangle_tile_base(n, 0) == 0
+        assert L.ldx_triangle_tile_base(n, T) == L.ldx_triangle_units(n)
+        if n > 1:
+            assert L.ldx_triangle_unit_of(n, n - 1, 0) == (n - 1) // 8
+            assert L.ldx_triangle_unit_of(n, n - 1, n - 2) < L.ldx_triangle_units(n)
+    for h in (1, 128, 129, 1008, 5008):
+        assert L.ldx_n_chunks(h) == (h + 127) // 128
+    assert L.ldx_plane_bytes(10000, 5008) == 79 * 40 * 128 * 16
+    # cells >= pairs, with less than 4 % padding at the bench size
+    cells = L.ldx_triangle_units(10000) * 1024
+    assert 10000 * 9999 // 2 <= cells < 1.04 * 10000 * 9999 // 2
+
+
+def test_device_calls_fail_loudly_without_gpu():
+    """No GPU here: the product must raise, not compute on the CPU."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from ld_tools_amd import LdxError, PackedPanel
+    from ld_tools_amd.backend.calc_ld import calc_ld
+
+    with pytest.raises(LdxError):
+        PackedPanel.from_codes(np.zeros((4, 8), dtype=np.int8))
+    with pytest.raises(LdxError):
+        calc_ld([1, 0, 1, 0], [1, 1, 0, 0])
+    with pytest.raises(ZeroDivisionError):       # calc_ld.py:33 behaviour is decided before any device call
+        calc_ld([], [])
+
+
+def test_encode_codes_matches_list_count_semantics():
+    from ld_tools_amd import encode_codes
+
+    seq = [1, 0, None, 2, 1.0, 0.0, True, False, "1", float("nan"), -1, 1.5]
+    got = encode_codes(seq).tolist()
+    want = [1 if v == 1 else (0 if v == 0 else 2) for v in seq]
+    assert got == want == [1, 0, 2, 2, 1, 0, 1, 0, 2, 2, 2, 2]
+    assert encode_codes(seq).tolist().count(1) == seq.count(1)
+    assert encode_codes(seq).tolist().count(0) == seq.count(0)
+    # vectorised paths
+    assert encode_codes(np.array([0, 1, 2, 3, 1], dtype=np.int64)).tolist() == [0, 1, 2, 2, 1]
+    assert encode_codes(np.array([[0.0, 1.0], [np.nan, 2.0]])).tolist() == [[0, 1], [2, 2]]
+    assert encode_codes((1, 0, 1)).tolist() == [1, 0, 1]
+
+
+def test_unit_partition_covers_every_pair_once():
+    from ld_tools_amd import dist
+
+    for n, world in [(300, 1), (300, 2), (1000, 8), (129, 3), (5, 4)]:
+        seen = np.zeros((n, n), dtype=np.int32)
+        parts = dist.unit_partition(n, world)
+        assert parts[0][0] == 0 and parts[-1][1] == dist.triangle_units(n)
+        for (u0, u1) in parts:
+            r, c = dist.unit_cells(n, u0, u1)
+            np.add.at(seen, (r, c), 1)
+        want = np.tril(np.ones((n, n), dtype=np.int32), -1)
+        assert np.array_equal(seen, want)
+        sizes = [u1 - u0 for (u0, u1) in parts]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def test_slab_partition():
+    from ld_tools_amd import dist
+
+    for n, world in [(100000, 8), (10000, 8), (300, 2), (129, 4), (64, 2)]:
+        parts = dist.slab_partition(n, world)
+        assert parts[0][0] == 0 and parts[-1][1] == n
+        for (b0, e0), (b1, e1) in zip(parts, parts[1:]):
+            assert e0 == b1
+        for b, e in parts[:-1]:
+            assert b % 128 == 0 and (e % 128 == 0 or e == n)
+
+
+def test_synth_thresholds_and_positions():
+    from ld_tools_amd import synth
+
+    thr = synth.snp_thresholds(7, 0, 1000, 5008)
+    assert thr.dtype == np.uint64 and thr.min() > 0
+    p = thr.astype(np.float64) / 2.0 ** 64
+    assert p.min() >= 1 / 5008 - 1e-12 and p.max() <= 1 - 1 / 5008 + 1e-12
+    assert 0.35 < p.mean() < 0.65          # U-shaped around one half
+    pos = synth.synth_positions(5)
+    assert pos.tolist() == [1, 501, 1001, 1501, 2001]
+    assert synth.prob_to_thr(0.0) == 0 and synth.prob_to_thr(1.0) == 2 ** 64 - 1

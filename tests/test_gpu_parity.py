@@ -1,0 +1,369 @@
+"""GPU: the HIP path (through the C ABI) against the oracle and the golden vectors.
+
+Bar: bit-exact for counts, packed planes, the 4-decimal results (k = value * 10^4) and the int-0 /
+float-0.0 flags; 1e-6 (in fact ~1e-15) for the unrounded D' and r^2 floats.
+"""
+import numpy as np
+import pytest
+
+from conftest import PANELS, tri_pairs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a HIP device")
+    import ld_tools_amd  # noqa: F401  (raises if libldx.so is missing: no fallback)
+    from ld_tools_amd import _lib
+
+    buf = __import__("ctypes").create_string_buffer(64)
+    _lib.check(_lib.lib.ldx_device_arch(0, buf, 64))
+    assert buf.value.decode().startswith("gfx950"), buf.value
+    return torch.device("cuda", 0)
+
+
+def untile(plane_u8: np.ndarray, n_snps: int, n_hap: int) -> np.ndarray:
+    """tiled plane bytes -> bool [n_snps][n_hap]"""
+    slabs, chunks = (n_snps + 127) // 128, (n_hap + 127) // 128
+    by = plane_u8.reshape(slabs, chunks, 128, 16).transpose(0, 2, 1, 3).reshape(slabs * 128, chunks * 16)
+    bits = np.unpackbits(by, axis=1, bitorder="little")
+    return bits[:n_snps, :n_hap].astype(bool), bits
+
+
+def k_of(x32: np.ndarray) -> np.ndarray:
+    return np.rint(x32.astype(np.float64) * 1e4).astype(np.int64)
+
+
+def int0_of(x32: np.ndarray) -> np.ndarray:
+    return np.signbit(x32)
+
+
+def flags_of(ld32: np.ndarray) -> np.ndarray:
+    return (int0_of(ld32[:, 1]).astype(np.uint8) * 1) | (int0_of(ld32[:, 0]).astype(np.uint8) * 2)
+
+
+# ------------------------------------------------------------------ packing
+@pytest.mark.parametrize("name", list(PANELS))
+def test_pack_matches_oracle(gpu, name, panel_codes):
+    from ld_tools_amd import PackedPanel
+    from oracle import c_oracle
+
+    codes = panel_codes[name]
+    p = PackedPanel.from_codes(codes)
+    o = c_oracle.Panel(codes)
+    alt, alt_all = untile(p.alt.cpu().numpy(), p.n_snps, p.n_hap)
+    ref, ref_all = untile(p.ref.cpu().numpy(), p.n_snps, p.n_hap)
+    assert np.array_equal(alt, codes == 1) and np.array_equal(ref, codes == 0)
+    assert alt_all.sum() == (codes == 1).sum() and ref_all.sum() == (codes == 0).sum()   # pad bits / rows are zero
+    assert np.array_equal(p.alt_counts(), o.acnt) and np.array_equal(p.ref_counts(), o.rcnt)
+    npad = p.padded_snps
+    assert not p.acnt[p.n_snps:npad].any() and not p.fa[p.n_snps:npad].any()
+    n = float(p.n_hap)
+    assert np.array_equal(p.fa[: p.n_snps].cpu().numpy(), o.acnt / n)       # one IEEE division each
+    assert np.array_equal(p.fr[: p.n_snps].cpu().numpy(), o.rcnt / n)
+    assert np.array_equal(p.q[: p.n_snps].cpu().numpy(), (o.acnt / n) * (o.rcnt / n))
+    want_f4 = np.array([round(a / n, 4) for a in o.acnt.tolist()])
+    assert np.array_equal(p.alt_freq4().cpu().numpy(), want_f4)
+
+
+def test_pack_unaligned_rows_and_tile_plane(gpu):
+    import torch
+
+    from ld_tools_amd import PackedPanel, _lib
+    from ld_tools_amd.panel import _stream_ptr
+    from oracle import ld_oracle as orc
+
+    rng = np.random.RandomState(2)
+    codes = rng.choice(np.array([0, 1, 2], dtype=np.int8), size=(131, 333), p=[0.5, 0.45, 0.05])
+    p = PackedPanel.from_codes(codes)          # rows of 333 bytes: not 16-byte aligned -> byte path
+    alt, _ = untile(p.alt.cpu().numpy(), 131, 333)
+    assert np.array_equal(alt, codes == 1)
+    # row-major bit plane -> tiled (ldx_tile_plane_dev)
+    alt64, _ = orc.pack_planes(codes)
+    rm = torch.from_numpy(alt64.view(np.uint32).astype(np.uint32).view(np.int32).copy()).to(gpu)
+    tiled = torch.empty_like(p.alt)
+    cnt = torch.empty_like(p.acnt)
+    _lib.check(_lib.lib.ldx_tile_plane_dev(rm.data_ptr(), 131, 333, rm.shape[1], tiled.data_ptr(), cnt.data_ptr(),
+                                           _stream_ptr()))
+    assert torch.equal(tiled, p.alt) and torch.equal(cnt, p.acnt)
+
+
+def test_synth_device_equals_host(gpu):
+    from ld_tools_amd import synth
+
+    for (n, h, seed, miss, off) in [(96, 5008, 20261003, 0.0, 0), (70, 1008, 7, 0.01, 0), (50, 333, 1, 0.02, 45)]:
+        dev = synth.synth_codes_device(n, h, seed=seed, miss=miss, snp_offset=off).cpu().numpy()
+        host = synth.synth_codes_host(n, h, seed=seed, miss=miss, snp_offset=off)
+        assert np.array_equal(dev, host), (n, h, seed)
+
+
+# ------------------------------------------------------------------ counts (bit-exact contract)
+@pytest.mark.parametrize("name", list(PANELS))
+def test_pair_counts_match_golden(gpu, name, panel_codes, panels_golden):
+    from ld_tools_amd import PackedPanel, pair_counts
+
+    p = PackedPanel.from_codes(panel_codes[name])
+    n11 = pair_counts(p).cpu().numpy().view(np.uint32)
+    rows, cols = tri_pairs(p.n_snps)
+    assert np.array_equal(n11[rows, cols], panels_golden[name + ".n11"])     # vs the reference itself
+    assert np.array_equal(n11, n11.T)
+    assert np.array_equal(np.diag(n11), p.alt_counts())
+
+
+def test_pair_counts_rectangular_two_panels(gpu):
+    from ld_tools_amd import PackedPanel, pair_counts, synth
+    from oracle import c_oracle
+
+    a = synth.synth_codes_host(300, 1008, seed=5, miss=0.01)
+    b = synth.synth_codes_host(137, 1008, seed=6, miss=0.0)
+    got = pair_counts(PackedPanel.from_codes(a), PackedPanel.from_codes(b)).cpu().numpy().view(np.uint32)
+    o = c_oracle.Panel(np.concatenate([a, b]))
+    assert np.array_equal(got, o.pair_counts(0, 300, 300, 437))
+
+
+# ------------------------------------------------------------------ epilogue (vs the reference's own outputs)
+def test_epilogue_small_n_exhaustive(gpu, small_n):
+    from ld_tools_amd import ld_from_counts
+    from oracle import c_oracle
+
+    counts = small_n["counts"].astype(np.uint32)
+    for n in np.unique(counts[:, 0]):
+        m = counts[:, 0] == n
+        c = counts[m]
+        raw, rnd, flags = ld_from_counts(int(n), c[:, 1], c[:, 2], c[:, 3], c[:, 4], c[:, 5])
+        rnd = rnd.cpu().numpy()
+        assert np.array_equal(k_of(rnd[:, 0]), small_n["k_rsq"][m])          # 4-decimal r^2, exact
+        assert np.array_equal(k_of(rnd[:, 1]), small_n["k_dp"][m])           # 4-decimal D', exact
+        assert np.array_equal(flags.cpu().numpy(), small_n["flags"][m])      # int 0 vs float 0.0
+        assert np.array_equal(flags_of(rnd), small_n["flags"][m])            # ... also encoded as -0.0f
+        assert np.array_equal(rnd[:, 0], (small_n["k_rsq"][m] / 1e4).astype(np.float32))
+        o = c_oracle.ld_from_counts_v(int(n), c[:, 1], c[:, 2], c[:, 3], c[:, 4], c[:, 5], libm_pow=True)
+        raw = raw.cpu().numpy()
+        assert np.array_equal(raw[:, 1], o[1])                               # D' is bit-identical
+        assert np.allclose(raw[:, 0], o[0], rtol=1e-15, atol=0)              # r^2: d*d vs pow(d,2): <= 2 ulp
+        assert np.max(np.abs(raw[:, 0] - o[0]), initial=0) <= 1e-6
+
+
+def test_epilogue_kat(gpu, kat):
+    from ld_tools_amd import ld_from_counts
+
+    for item in kat["tuples"]:
+        n, n11, a1, r1, a2, r2 = item["counts"]
+        raw, rnd, flags = ld_from_counts(n, [n11], [a1], [r1], [a2], [r2])
+        e = item["expect"]
+        f = int(flags[0])
+        # the float32 cell holds k = value * 10^4 exactly up to k < 2^24 (values below 1677.7); the D' >> 1
+        # tuples (a + r < n with a vanishing bound) are checked through the unrounded fp64 output instead
+        pick = lambda col, w: round(float(rnd[0, col]), 4) if w < 1000 else round(float(raw[0, col]), 4)  # noqa: E731
+        got_r = 0 if f & 2 else pick(0, e["r_square"])
+        got_d = 0 if f & 1 else pick(1, e["d_prime"])
+        assert got_r == e["r_square"] and type(got_r) is type(e["r_square"]), item
+        assert got_d == e["d_prime"] and type(got_d) is type(e["d_prime"]), item
+
+
+# ------------------------------------------------------------------ ld_triangle
+@pytest.mark.parametrize("name", list(PANELS))
+def test_triangle_matches_golden(gpu, name, panel_codes, panels_golden):
+    from ld_tools_amd import PackedPanel, ld_triangle
+    from oracle import c_oracle
+
+    codes = panel_codes[name]
+    p = PackedPanel.from_codes(codes)
+    res = ld_triangle(p, want_raw=True, want_n11=True)
+    rows, cols = tri_pairs(p.n_snps)
+    idx = res.cell_index(rows, cols)
+    ld32 = res.ld32.cpu().numpy()[idx]
+    assert np.array_equal(res.n11.cpu().numpy().view(np.uint32)[idx], panels_golden[name + ".n11"])
+    assert np.array_equal(k_of(ld32[:, 0]), panels_golden[name + ".k_rsq"])
+    assert np.array_equal(k_of(ld32[:, 1]), panels_golden[name + ".k_dp"])
+    assert np.array_equal(flags_of(ld32), panels_golden[name + ".flags"])
+    o = c_oracle.Panel(codes).triangle(libm_pow=True)
+    raw = res.raw.cpu().numpy()[idx]
+    assert np.max(np.abs(raw[:, 0] - o["rsq_raw"][rows, cols])) <= 1e-6
+    assert np.array_equal(raw[:, 1], o["dp_raw"][rows, cols])
+    # every other cell of the strip output (row <= col, pad rows) is zero
+    mask = np.ones(len(res.ld32), dtype=bool)
+    mask[idx] = False
+    assert not res.ld32.cpu().numpy()[mask].any()
+
+
+def test_triangle_dense_and_thresholds(gpu, drivers, panel_codes):
+    from ld_tools_amd import PackedPanel, ld_triangle
+
+    p = PackedPanel.from_codes(panel_codes[drivers["panel"]])
+    res = ld_triangle(p)
+    for key, want in drivers["triangle"].items():
+        measure, thres = key.split("|")
+        thres = None if thres == "None" else float(thres)
+        dense = res.dense(measure, thres).cpu().numpy()
+        for i, wrow in enumerate(want):
+            for j, w in enumerate(wrow):
+                g = dense[i, j]
+                if isinstance(w, int):
+                    assert g == 0 and np.signbit(g), (key, i, j)          # int 0 <-> -0.0f
+                else:
+                    assert not (g == 0 and np.signbit(g)) and round(float(g), 4) == w, (key, i, j, g, w)
+
+
+def test_triangle_sharded_units_equal_full(gpu):
+    from ld_tools_amd import PackedPanel, dist, ld_triangle, synth
+
+    p = PackedPanel.from_codes(synth.synth_codes_device(700, 1008, seed=4, miss=0.005))
+    full = ld_triangle(p, want_n11=True)
+    for world in (2, 3, 8):
+        parts = dist.unit_partition(700, world)
+        pieces = [ld_triangle(p, unit_range=r, want_n11=True) for r in parts]
+        import torch
+        assert torch.equal(torch.cat([x.ld32 for x in pieces]).view(torch.int32), full.ld32.view(torch.int32))
+        assert torch.equal(torch.cat([x.n11 for x in pieces]), full.n11)
+
+
+@pytest.mark.parametrize("n_snps,n_hap", [(1, 64), (2, 1), (2, 128), (9, 129), (129, 37), (257, 2000), (130, 10240)])
+def test_triangle_edge_shapes(gpu, n_snps, n_hap):
+    from ld_tools_amd import PackedPanel, ld_triangle, synth
+    from oracle import c_oracle
+
+    codes = synth.synth_codes_host(n_snps, n_hap, seed=12, miss=0.03)
+    codes[0] = 1                      # a monomorphic ALT variant
+    if n_snps > 2:
+        codes[2] = 0                  # and a monomorphic REF one
+    p = PackedPanel.from_codes(codes)
+    res = ld_triangle(p, want_raw=True, want_n11=True)
+    rows, cols = tri_pairs(n_snps)
+    if n_snps == 1:
+        assert not res.ld32.cpu().numpy().any()
+        return
+    idx = res.cell_index(rows, cols)
+    o = c_oracle.Panel(codes).triangle(libm_pow=False)
+    ld32 = res.ld32.cpu().numpy()[idx]
+    assert np.array_equal(res.n11.cpu().numpy().view(np.uint32)[idx], o["n11"][rows, cols])
+    assert np.array_equal(k_of(ld32[:, 0]), np.rint(o["rsq_rnd"][rows, cols] * 1e4).astype(np.int64))
+    assert np.array_equal(k_of(ld32[:, 1]), np.rint(o["dp_rnd"][rows, cols] * 1e4).astype(np.int64))
+    assert np.array_equal(flags_of(ld32), o["flags"][rows, cols])
+    raw = res.raw.cpu().numpy()[idx]
+    assert np.array_equal(raw[:, 0], o["rsq_raw"][rows, cols]) and np.array_equal(raw[:, 1], o["dp_raw"][rows, cols])
+
+
+def test_too_many_haplotypes_is_an_error(gpu):
+    from ld_tools_amd import LdxError, PackedPanel
+
+    with pytest.raises(LdxError):
+        PackedPanel.empty(4, 10241)
+
+
+def test_triangle_bench_size_against_oracle_rows(gpu):
+    """C2 (10 000 x 5008): three bands of rows against the C oracle, plus size-independent properties."""
+    from ld_tools_amd import PackedPanel, ld_triangle, pair_counts, synth
+    from oracle import c_oracle
+
+    n, h = 10000, 5008
+    codes_d = synth.synth_codes_device(n, h, seed=synth.BENCH_SEED)
+    p = PackedPanel.from_codes(codes_d)
+    res = ld_triangle(p, want_n11=True)
+    codes = codes_d.cpu().numpy()
+    o = c_oracle.Panel(codes)
+    assert np.array_equal(p.alt_counts(), o.acnt)
+    ld32 = res.ld32.cpu().numpy()
+    n11 = res.n11.cpu().numpy().view(np.uint32)
+    for (r0, r1) in [(1, 40), (5000, 5024), (9990, 10000)]:
+        t = o.triangle(r0, r1, libm_pow=True)
+        rows = np.concatenate([np.full(i, i, dtype=np.int64) for i in range(r0, r1)])
+        cols = np.concatenate([np.arange(i, dtype=np.int64) for i in range(r0, r1)])
+        idx = res.cell_index(rows, cols)
+        assert np.array_equal(n11[idx], t["n11"][rows, cols])
+        assert np.array_equal(k_of(ld32[idx, 0]), np.rint(t["rsq_rnd"][rows, cols] * 1e4).astype(np.int64))
+        assert np.array_equal(k_of(ld32[idx, 1]), np.rint(t["dp_rnd"][rows, cols] * 1e4).astype(np.int64))
+        assert np.array_equal(flags_of(ld32[idx]), t["flags"][rows, cols])
+    # properties over ALL cells: total n11 mass equals sum_h C(k_h, 2), k_h = ALT count of haplotype column h
+    colsum = (codes == 1).sum(axis=0).astype(np.int64)
+    assert int(n11.astype(np.int64).sum()) == int((colsum * (colsum - 1) // 2).sum())
+    # values in range, and a strip row agrees with the rectangular n11 kernel
+    rng = np.random.RandomState(0)
+    rr = rng.randint(1, n, size=200000)
+    cc = (rng.random_sample(200000) * rr).astype(np.int64)
+    valid = ld32[res.cell_index(rr, cc)]
+    assert (valid[:, 0] >= 0).all() and (valid[:, 0] <= 1.0001).all() and (valid[:, 1] <= 1.0001).all()
+    sub = PackedPanel.from_codes(codes[4096:4096 + 256])
+    blk = pair_counts(sub, p).cpu().numpy().view(np.uint32)
+    rows = np.repeat(np.arange(4096, 4352), 4096)
+    cols = np.tile(np.arange(4096), 256)
+    assert np.array_equal(n11[res.cell_index(rows, cols)], blk[:, :4096].ravel())
+
+
+# ------------------------------------------------------------------ ld_area
+def test_area_matches_golden_drivers(gpu, drivers, panel_codes):
+    from ld_tools_amd import PackedPanel, ld_area
+
+    p = PackedPanel.from_codes(panel_codes[drivers["panel"]])
+    f4 = p.alt_freq4().cpu().numpy()
+    pos = drivers["positions"]
+    for case in drivers["area"]:
+        hits = ld_area(p, pos, case["queries"], case["flank"], case["measure"], case["thres"])
+        want = sorted((tuple(h) for h in case["hits"]), key=lambda h: (h[0], h[1]))
+        assert len(hits) == len(want), case["flank"]
+        q = hits.query.cpu().numpy()
+        o = hits.oppos.cpu().numpy()
+        ld = hits.ld32.cpu().numpy()
+        for k, w in enumerate(want):
+            assert (q[k], o[k]) == (w[0], w[1])
+            assert f4[o[k]] == w[2] and pos[o[k]] - pos[q[k]] == w[5]
+            for col, wv in ((0, w[3]), (1, w[4])):
+                g = ld[k, col]
+                if isinstance(wv, int):
+                    assert g == 0 and np.signbit(g)
+                else:
+                    assert not (g == 0 and np.signbit(g)) and round(float(g), 4) == wv
+
+
+def test_area_banded_against_oracle(gpu):
+    from ld_tools_amd import PackedPanel, ld_area, synth
+    from oracle import c_oracle
+
+    n, h = 3000, 1008
+    codes = synth.synth_codes_host(n, h, seed=8, miss=0.002)
+    pos = synth.synth_positions(n, step=500)
+    p = PackedPanel.from_codes(codes)
+    o = c_oracle.Panel(codes)
+    for (queries, flank, measure, thres) in [(None, 20000, "r_square", 0.8), (list(range(0, n, 7)), 150000, "d_prime", 1.0),
+                                             (None, 3000, "r_square", 0.0)]:
+        hits = ld_area(p, pos, queries, flank, measure, thres)
+        qs = np.arange(n) if queries is None else np.array(queries)
+        hq, ho, hr, hd, hf = o.area(pos, qs, flank, 0 if measure == "r_square" else 1, thres, libm_pow=True)
+        assert len(hits) == len(hq)
+        assert np.array_equal(hits.query.cpu().numpy(), hq) and np.array_equal(hits.oppos.cpu().numpy(), ho)
+        ld = hits.ld32.cpu().numpy()
+        assert np.array_equal(k_of(ld[:, 0]), np.rint(hr * 1e4).astype(np.int64))
+        assert np.array_equal(k_of(ld[:, 1]), np.rint(hd * 1e4).astype(np.int64))
+        assert np.array_equal(flags_of(ld), hf)
+        # pairs evaluated = window populations
+        lo = np.searchsorted(pos, np.maximum(pos[qs] - flank, 0), side="right")
+        hi = np.searchsorted(pos, pos[qs] + flank, side="right")
+        assert hits.n_pairs == int((hi - lo).sum() - (flank > 0) * len(qs))
+
+
+# ------------------------------------------------------------------ calc_ld drop-in
+def test_calc_ld_dropin(gpu, kat):
+    from ld_tools_amd.backend.calc_ld import calc_ld, calc_ld_full
+
+    for item in kat["literal"]:
+        got = calc_ld(item["g1"], item["g2"])
+        assert list(got) == ["r_square", "d_prime", "var_1_alt_freq", "var_2_alt_freq"]
+        for k, w in item["expect"].items():
+            assert got[k] == w and type(got[k]) is type(w), (item, k, got[k])
+        assert str(got) == str(item["expect"])
+    for item in kat["tuples"][:12]:
+        n, n11, a1, r1, a2, r2 = item["counts"]
+        g1 = [1] * n11 + [1] * (a1 - n11) + [0] * (n - a1)
+        g2 = [1] * n11 + [0] * (a1 - n11) + [1] * (a2 - n11) + [0] * (n - a1 - a2 + n11)
+        if r1 != n - a1 or r2 != n - a2 or len(g2) != n:
+            continue
+        got, counts, raw, flags = calc_ld_full(g1, g2)
+        assert counts == (n, n11, a1, r1, a2, r2)
+        assert str(got) == str(item["expect"])
+    with pytest.raises(ZeroDivisionError):
+        calc_ld([], [1])
+    assert str(calc_ld(np.array([1, 0, 1, 0]), np.array([1, 1, 0, 0]))) == str(calc_ld([1, 0, 1, 0], [1, 1, 0, 0]))
