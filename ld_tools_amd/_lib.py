@@ -42,7 +42,25 @@ def _load() -> C.CDLL:
                     f"ld_tools_amd: {LIB_PATH} is missing and could not be built ({exc}); "
                     "run `python -m ld_tools_amd.build` on a machine with hipcc. "
                     "There is no CPU fallback.") from exc
+    _share_hip_runtime()
     return C.CDLL(str(LIB_PATH))
+
+
+def _share_hip_runtime() -> None:
+    """Make libldx.so bind to the HIP runtime torch uses (one runtime per process).
+
+    torch-ROCm ships its own libamdhip64.so.7 / libhsa-runtime64; a second copy from /opt/rocm in the
+    same process cannot open the device ("no ROCm-capable device is detected").  libldx.so only NEEDs
+    the soname libamdhip64.so.7, so loading torch's copy first (RTLD_GLOBAL) makes the dynamic loader
+    resolve it to that one.  Without torch (a plain C host) the library's RUNPATH finds /opt/rocm.
+    """
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        return
+    cand = Path(torch.__file__).resolve().parent / "lib" / "libamdhip64.so"
+    if cand.exists():
+        C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
 
 
 lib = _load()

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output (kernel stats + PMC passes) into a short text summary."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+root = sys.argv[1]
+
+
+def rows(pattern):
+    for f in glob.glob(os.path.join(root, pattern), recursive=True):
+        with open(f, newline="") as fh:
+            for r in csv.DictReader(fh):
+                yield f, r
+
+
+print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
+seen = False
+for f, r in rows("trace/**/*kernel_stats.csv"):
+    seen = True
+    print(f"{r.get('Name', '')[:70]:70s} calls={r.get('Calls')} total_ns={r.get('TotalDurationNs')} "
+          f"avg_ns={r.get('AverageNs')} pct={r.get('Percentage')}")
+if not seen:
+    dur = defaultdict(list)
+    for f, r in rows("trace/**/*kernel_trace.csv"):
+        dur[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
+        print(f"{k[:70]:70s} calls={len(v)} total_ns={sum(v)} avg_ns={sum(v) / len(v):.0f}")
+
+for tag in ("pmc_fetch", "pmc_write", "pmc_sq"):
+    acc = defaultdict(lambda: defaultdict(list))
+    for f, r in rows(f"{tag}/**/*counter_collection.csv"):
+        acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    if acc:
+        print(f"== {tag} (per dispatch mean) ==")
+        for k, cs in acc.items():
+            if "triangle" not in k and "pack" not in k:
+                continue
+            print(k[:90])
+            for c, v in cs.items():
+                print(f"    {c:24s} n={len(v):4d} mean={sum(v) / len(v):.4g}")
