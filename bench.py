@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--snps", type=int, default=0, help="panel size (default: 10000 * sqrt(gpus))")
     ap.add_argument("--haps", type=int, default=5008)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--force-dist", action="store_true", help="run the sharded path (process group + all-gather) even at world 1")
     ap.add_argument("--cpu-sample-snps", type=int, default=224)
     return ap.parse_args()
 
@@ -99,10 +101,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; there is no CPU path")
+    if args.backend != "nccl":
+        local_rank %= torch.cuda.device_count()       # gloo rehearsal: several ranks may share one card
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        if "RANK" not in os.environ:                  # --force-dist without a launcher: a one-rank group
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from ld_tools_amd import PackedPanel, dist as ldist, ld_triangle, ops, synth
     from ld_tools_amd._lib import lib
@@ -125,13 +137,13 @@ def main():
         local = PackedPanel.from_codes(codes_local)
     u0, u1 = ldist.unit_partition(n_snps, world)[rank]
     out = None
-    panel = local if world == 1 else None
+    panel = None if use_dist else local
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
     def step(k=None):
         nonlocal out, panel
-        if world > 1:
+        if use_dist:
             panel = ldist.all_gather_panel(local, n_snps, n_hap)      # the exchange step (RCCL all-gather)
         if k is not None:
             ev0[k].record()
@@ -140,7 +152,7 @@ def main():
             ev1[k].record()
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -221,7 +233,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(host, args.cpu_sample_snps)
     if rank == 0:
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Ad-hoc GPU measurements used while tuning (not part of the product or of bench.py's contract).
+
+    python tools/gpu_exp.py counts     # n11-only kernel on a 10k x 10k block (counting without the epilogue)
+    python tools/gpu_exp.py area       # configs[2]: 100k SNPs, +-500 kb windows, r2 >= 0.8
+    python tools/gpu_exp.py tri100k    # configs[3] on one GPU: 100k x 5008 triangle
+    python tools/gpu_exp.py eur        # configs[4] shape on the popcount path: 50k x 1008
+    python tools/gpu_exp.py pack       # pack kernel bandwidth
+"""
+import json
+import sys
+import time
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+
+import torch  # noqa: E402
+
+from ld_tools_amd import PackedPanel, ld_area, ld_triangle, pair_counts, synth  # noqa: E402
+
+
+def timed(fn, reps=5, warm=1):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+def main():
+    what = sys.argv[1]
+    out = {"exp": what}
+    if what == "counts":
+        n, h = 10000, 5008
+        p = PackedPanel.from_codes(synth.synth_codes_device(n, h))
+        ms = timed(lambda: pair_counts(p), reps=5)
+        out.update(ms=ms, pairs=n * n, pairs_per_s=n * n / (ms * 1e-3), lane_ops_T=n * n * 314 / (ms * 1e-3) / 1e12)
+    elif what == "area":
+        n, h = 100000, 5008
+        p = PackedPanel.from_codes(synth.synth_codes_device(n, h))
+        pos = synth.synth_positions(n, step=500)
+        t0 = time.perf_counter()
+        hits = ld_area(p, pos, None, 500000, "r_square", 0.8)
+        torch.cuda.synchronize()
+        first = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        hits = ld_area(p, pos, None, 500000, "r_square", 0.8, hit_capacity=len(hits) + 600000)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out.update(first_call_s=first, s=dt, ordered_pairs=hits.n_pairs, hits=len(hits),
+                   ordered_pairs_per_s=hits.n_pairs / dt)
+    elif what == "tri100k":
+        n, h = 100000, 5008
+        p = PackedPanel.from_codes(synth.synth_codes_device(n, h))
+        res = ld_triangle(p)
+        ms = timed(lambda: ld_triangle(p, out=res), reps=3)
+        out.update(ms=ms, pairs=p.n_pairs, pairs_per_s=p.n_pairs / (ms * 1e-3), out_gb=res.ld32.numel() * 4 / 1e9)
+    elif what == "eur":
+        n, h = 50000, 1008
+        p = PackedPanel.from_codes(synth.synth_codes_device(n, h))
+        res = ld_triangle(p)
+        ms = timed(lambda: ld_triangle(p, out=res), reps=3)
+        out.update(ms=ms, pairs=p.n_pairs, pairs_per_s=p.n_pairs / (ms * 1e-3))
+    elif what == "pack":
+        n, h = 100000, 5008
+        codes = synth.synth_codes_device(n, h)
+        p = PackedPanel.empty(n, h)
+        ms = timed(lambda: p.pack_from(codes), reps=5)
+        out.update(ms=ms, gbps_in=n * h / (ms * 1e-3) / 1e9)
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
