@@ -131,6 +131,15 @@ int ldx_ld_from_counts_dev(uint32_t n, size_t m, const uint32_t *n11, const uint
 int ldx_triangle_dev(const void *alt, const double *fa, const double *fr, const double *q,
                      uint32_t n_snps, uint32_t n_hap, uint64_t unit_begin, uint64_t unit_end,
                      ldx_ld32 *out, ldx_ld64 *out_raw, uint32_t *out_n11, void *stream);
+/* Which kernel ldx_triangle_dev launches.  Both produce identical results (tests compare them cell for
+ * cell): POPCOUNT = v_and_b32 + v_bcnt_u32_b32 on the bit-packed rows; MFMA = int8 G.G^T on the matrix
+ * cores with the bits expanded to bytes in registers.  AUTO picks the one that measures faster. */
+#define LDX_PATH_AUTO 0
+#define LDX_PATH_POPCOUNT 1
+#define LDX_PATH_MFMA 2
+int ldx_set_triangle_path(int path);
+int ldx_get_triangle_path(void);
+
 /* Strip output -> dense row-major float32 [n_rows][ld] matrix of one measure with the
  * ld_two_dim semantics of ld_triangle.py:114,223-230: cell = rounded measure, or 0 when
  * row <= col or (has_thres and rounded measure < thres).  Rows [row_begin, row_end). */

@@ -88,6 +88,8 @@ SIGNATURES = {
     "ldx_pair_counts_dev": (_int, [_vp, _u32, _vp, _u32, _u32, _vp, _sz, _vp]),
     "ldx_ld_from_counts_dev": (_int, [_u32, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ldx_triangle_dev": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u64, _u64, _vp, _vp, _vp, _vp]),
+    "ldx_set_triangle_path": (_int, [_int]),
+    "ldx_get_triangle_path": (_int, []),
     "ldx_triangle_dense_dev": (_int, [_vp, _u32, _int, _int, _dbl, _u32, _u32, _vp, _sz, _vp]),
     "ldx_area_dev": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _u32, _i64, _int, _dbl, _vp, _u64,
                             _vp, _vp, _sz, _vp]),

@@ -16,7 +16,7 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libldx.so"
-SOURCES = ["ldx_api.hip", "ldx_pack.hip", "ldx_pairs.hip", "ldx_area.hip", "ldx_synth.hip"]
+SOURCES = ["ldx_api.hip", "ldx_pack.hip", "ldx_pairs.hip", "ldx_mfma.hip", "ldx_area.hip", "ldx_synth.hip"]
 HEADERS = [CSRC / "ldx_common.h", CSRC / "ldx_tile.h", PKG.parent / "include" / "ldx.h"]
 
 # -ffp-contract=off: the epilogue must round every product and sum separately (calc_ld.py:50);

@@ -19,6 +19,11 @@ void set_error(const char *fmt, ...);
 // ld_triangle.py:224) becomes the exact integer test k >= thres_to_k(thres).
 double thres_to_k(double thres);
 
+// ld_triangle on the matrix cores (ldx_mfma.hip); same contract as ldx_triangle_dev after argument checks
+int triangle_mfma(const void *alt, const double *fa, const double *fr, const double *q, uint32_t n_snps, uint32_t n_hap,
+                  uint64_t unit_begin, uint64_t unit_end, ldx_ld32 *out, ldx_ld64 *out_raw, uint32_t *out_n11,
+                  hipStream_t s);
+
 #define LDX_HIP(call)                                                                       \
     do {                                                                                    \
         hipError_t e_ = (call);                                                             \

@@ -201,6 +201,17 @@ __global__ void __launch_bounds__(1024) probe_andpop_kernel(uint32_t *__restrict
 
 using namespace ldx;
 
+static int g_triangle_path = LDX_PATH_AUTO;
+
+extern "C" int ldx_set_triangle_path(int path)
+{
+    LDX_REQUIRE(path == LDX_PATH_AUTO || path == LDX_PATH_POPCOUNT || path == LDX_PATH_MFMA, "unknown path");
+    g_triangle_path = path;
+    return LDX_OK;
+}
+
+extern "C" int ldx_get_triangle_path(void) { return g_triangle_path; }
+
 static size_t tile_lds_bytes(uint32_t nchunks) { return (size_t)nchunks * kSlab * 16u; }
 
 static int ensure_lds(const void *kernel, size_t bytes)
@@ -254,6 +265,8 @@ extern "C" int ldx_triangle_dev(const void *alt, const double *fa, const double 
     if (unit_end > U) unit_end = U;
     if (unit_begin >= unit_end) return LDX_OK;
     hipStream_t s = (hipStream_t)stream;
+    if (g_triangle_path == LDX_PATH_MFMA || g_triangle_path == LDX_PATH_AUTO)
+        return triangle_mfma(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end, out, out_raw, out_n11, s);
     if (out_raw && out_n11)
         return launch_triangle<true, true>(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end, out, out_raw, out_n11, s);
     if (out_raw)

@@ -21,6 +21,19 @@ from ._lib import MEASURES, UNIT_PAIRS, check, lib
 from .panel import PackedPanel, _ptr, _stream_ptr
 
 
+PATHS = {"auto": 0, "popcount": 1, "mfma": 2}
+
+
+def set_triangle_path(name: str) -> None:
+    """Choose the kernel behind ld_triangle: 'popcount', 'mfma' or 'auto' (results are identical)."""
+    check(lib.ldx_set_triangle_path(PATHS[name]), "ldx_set_triangle_path")
+
+
+def get_triangle_path() -> str:
+    code = lib.ldx_get_triangle_path()
+    return next(k for k, v in PATHS.items() if v == code)
+
+
 # --------------------------------------------------------------------------- triangle
 @dataclass
 class TriangleResult:

@@ -26,6 +26,16 @@ def gpu():
     return torch.device("cuda", 0)
 
 
+@pytest.fixture(params=["popcount", "mfma"])
+def path(request, gpu):
+    """Run a triangle test once per kernel: AND+BCNT on the VALU, and int8 MFMA."""
+    from ld_tools_amd import ops
+
+    ops.set_triangle_path(request.param)
+    yield request.param
+    ops.set_triangle_path("auto")
+
+
 def untile(plane_u8: np.ndarray, n_snps: int, n_hap: int) -> np.ndarray:
     """tiled plane bytes -> bool [n_snps][n_hap]"""
     slabs, chunks = (n_snps + 127) // 128, (n_hap + 127) // 128
@@ -167,7 +177,7 @@ def test_epilogue_kat(gpu, kat):
 
 # ------------------------------------------------------------------ ld_triangle
 @pytest.mark.parametrize("name", list(PANELS))
-def test_triangle_matches_golden(gpu, name, panel_codes, panels_golden):
+def test_triangle_matches_golden(gpu, path, name, panel_codes, panels_golden):
     from ld_tools_amd import PackedPanel, ld_triangle
     from oracle import c_oracle
 
@@ -191,7 +201,7 @@ def test_triangle_matches_golden(gpu, name, panel_codes, panels_golden):
     assert not res.ld32.cpu().numpy()[mask].any()
 
 
-def test_triangle_dense_and_thresholds(gpu, drivers, panel_codes):
+def test_triangle_dense_and_thresholds(gpu, path, drivers, panel_codes):
     from ld_tools_amd import PackedPanel, ld_triangle
 
     p = PackedPanel.from_codes(panel_codes[drivers["panel"]])
@@ -209,7 +219,7 @@ def test_triangle_dense_and_thresholds(gpu, drivers, panel_codes):
                     assert not (g == 0 and np.signbit(g)) and round(float(g), 4) == w, (key, i, j, g, w)
 
 
-def test_triangle_sharded_units_equal_full(gpu):
+def test_triangle_sharded_units_equal_full(gpu, path):
     from ld_tools_amd import PackedPanel, dist, ld_triangle, synth
 
     p = PackedPanel.from_codes(synth.synth_codes_device(700, 1008, seed=4, miss=0.005))
@@ -223,7 +233,7 @@ def test_triangle_sharded_units_equal_full(gpu):
 
 
 @pytest.mark.parametrize("n_snps,n_hap", [(1, 64), (2, 1), (2, 128), (9, 129), (129, 37), (257, 2000), (130, 10240)])
-def test_triangle_edge_shapes(gpu, n_snps, n_hap):
+def test_triangle_edge_shapes(gpu, path, n_snps, n_hap):
     from ld_tools_amd import PackedPanel, ld_triangle, synth
     from oracle import c_oracle
 
@@ -248,6 +258,29 @@ def test_triangle_edge_shapes(gpu, n_snps, n_hap):
     assert np.array_equal(raw[:, 0], o["rsq_raw"][rows, cols]) and np.array_equal(raw[:, 1], o["dp_raw"][rows, cols])
 
 
+def test_popcount_and_mfma_kernels_agree_bitwise(gpu):
+    import torch
+
+    from ld_tools_amd import PackedPanel, ld_triangle, ops, synth
+
+    p = PackedPanel.from_codes(synth.synth_codes_device(1500, 5008, seed=21, miss=0.004))
+    ops.set_triangle_path("popcount")
+    a = ld_triangle(p, want_raw=True, want_n11=True)
+    ops.set_triangle_path("mfma")
+    b = ld_triangle(p, want_raw=True, want_n11=True)
+    ops.set_triangle_path("auto")
+    assert torch.equal(a.n11, b.n11)
+    assert torch.equal(a.ld32.view(torch.int32), b.ld32.view(torch.int32))      # incl. the -0.0f int-0 marks
+    assert torch.equal(a.raw.view(torch.int64), b.raw.view(torch.int64))
+    # ragged unit ranges (not multiples of 8 small units) on the MFMA path
+    ops.set_triangle_path("mfma")
+    parts = [(0, 13), (13, 1001), (1001, p.n_units)]
+    pieces = [ld_triangle(p, unit_range=r, want_n11=True) for r in parts]
+    ops.set_triangle_path("auto")
+    assert torch.equal(torch.cat([x.n11 for x in pieces]), a.n11)
+    assert torch.equal(torch.cat([x.ld32 for x in pieces]).view(torch.int32), a.ld32.view(torch.int32))
+
+
 def test_too_many_haplotypes_is_an_error(gpu):
     from ld_tools_amd import LdxError, PackedPanel
 
@@ -255,7 +288,7 @@ def test_too_many_haplotypes_is_an_error(gpu):
         PackedPanel.empty(4, 10241)
 
 
-def test_triangle_bench_size_against_oracle_rows(gpu):
+def test_triangle_bench_size_against_oracle_rows(gpu, path):
     """C2 (10 000 x 5008): three bands of rows against the C oracle, plus size-independent properties."""
     from ld_tools_amd import PackedPanel, ld_triangle, pair_counts, synth
     from oracle import c_oracle
