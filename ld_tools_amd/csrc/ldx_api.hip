@@ -28,6 +28,21 @@ double thres_to_k(double thres)
     return k;
 }
 
+bool check_recip(uint32_t n)
+{
+    static thread_local uint32_t last_ok = 0;
+    if (n == last_ok) return true;
+    const double nn = (double)n, rn = 1.0 / nn;
+    for (uint32_t c = 0; c <= n; ++c) {
+        const double cc = (double)c;
+        const double q = cc * rn;
+        const double r = fma(-q, nn, cc);
+        if (fma(r, rn, q) != cc / nn) return false;
+    }
+    last_ok = n;
+    return true;
+}
+
 }  // namespace ldx
 
 using namespace ldx;

@@ -110,4 +110,62 @@ __device__ inline ldx_ld32 round_pair(const LdRaw &r)
     return o;
 }
 
+// The mirror as one out-of-line call: the fallback of ld_pair_fast (rare) must not be inlined 16-128 times.
+static __device__ __noinline__ ldx_ld32 ld_pair_mirror(double f11, double fa1, double fr1, double q1, double fa2,
+                                                       double fr2)
+{
+    return round_pair(ld_epilogue(f11, fa1, fr1, q1, fa2, fr2));
+}
+
+// host: true iff div_by_n(c, n, 1/n) == c / n for every integer c in [0, n] (always, by Markstein's theorem;
+// checked anyway because the parity claim rests on it)
+bool check_recip(uint32_t n);
+
+// n11 / n exactly as one IEEE division (calc_ld.py:33) in three operations: q = c*rn, r = c - q*n (exact,
+// fma), q' = q + r*rn.  With rn = RN(1/n) this is the correctly rounded quotient (Markstein); the host checks
+// it against real divisions for every c in [0, n] before the first launch with a given n (ldx_check_recip).
+__device__ __forceinline__ double div_by_n(double c, double n, double rn)
+{
+    const double q = c * rn;
+    const double r = __builtin_fma(-q, n, c);
+    return __builtin_fma(r, rn, q);
+}
+
+// ---- fast epilogue for the 8-byte/pair output: same k = round(x, 4) * 10^4 and same int-0 marks as the
+// mirror above, at roughly half the instructions.
+//   * d, the sign branch and `bound` are computed exactly as the mirror does (they decide the int-0 marks
+//     and which bound applies);
+//   * the two quotients D' = d / bound and r^2 = d*d / den share ONE reciprocal 1/(bound*den) (v_rcp_f64 + two
+//     Newton steps): relative error ~1e-15 instead of correctly rounded;
+//   * y = x*1e4 is rounded with rint; the mirror's value differs from ours by < 1e-8 in y, so both round to
+//     the same integer unless y is within 1e-6 of a half-integer (or absurdly large): only then `slow` is
+//     set and the caller recomputes that pair with ld_pair_mirror.  Exact ties (e.g. D' = 27/32) always
+//     take the slow path, so the reference's tie behaviour (decided by its own rounding errors) is kept.
+__device__ __forceinline__ ldx_ld32 ld_pair_fast(double f11, double fa1, double fr1, double q1, double fa2,
+                                                 double fr2, bool &slow)
+{
+    const double p = fa1 * fa2;
+    const double d = f11 - p;
+    const double m1 = fa1 * fr2, m2 = fr1 * fa2;
+    const double dmax = m1 < m2 ? m1 : m2;
+    const double m3 = fr1 * fr2;
+    const double dmin = p < m3 ? p : m3;
+    const double bound = d >= 0.0 ? dmax : -dmin;            // signed like the mirror's
+    const double den = (q1 * fa2) * fr2;
+    const bool degenerate = bound == 0.0;                    // monomorphic variant: both results are int 0
+    const double t = degenerate ? 1.0 : bound * den;         // bound != 0 implies all four frequencies != 0
+    double r = __builtin_amdgcn_rcp(t);
+    r = __builtin_fma(r, __builtin_fma(-t, r, 1.0), r);
+    r = __builtin_fma(r, __builtin_fma(-t, r, 1.0), r);
+    const double yd = (d * (den * r)) * 1e4;                 // D' * 10^4   (den*r = 1/bound, sign included)
+    const double yr = ((d * d) * (bound * r)) * 1e4;         // r^2 * 10^4  (bound*r = 1/den > 0)
+    const double kd = __builtin_rint(yd), kr = __builtin_rint(yr);
+    const bool sure = __builtin_fabs(yd - kd) < 0.499999 && __builtin_fabs(yr - kr) < 0.499999 && yd < 1e9 && yr < 1e9;
+    slow = !degenerate && !sure;
+    ldx_ld32 o;
+    o.d_prime = encode32(degenerate ? 0.0 : kd, degenerate);
+    o.r_square = encode32(degenerate ? 0.0 : kr, degenerate || d == 0.0);   // d_prime == 0 <=> d == 0 here
+    return o;
+}
+
 }  // namespace ldx

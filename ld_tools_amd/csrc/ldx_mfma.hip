@@ -3,20 +3,28 @@
 //
 // Why: AND + BCNT run at 64 lanes/clk/CU (no packed form), i.e. 16 haplotype-pairs per lane-instruction;
 // the int8 MFMA does 1024 MACs/clk/SIMD -- 4x the VALU ceiling -- so the count moves to the matrix pipe
-// and the VALU is left with expanding bits to bytes and the epilogue.
+// and the VALU is left with expanding bits to bytes and with the epilogue.
 //
-// Structure (same persistent skeleton as triangle_kernel):
-//   * the j-tile (128 SNP rows, all chunks) sits in LDS still BIT-PACKED (80 KiB at 5008 haplotypes);
-//   * a wave's unit is 64 i-rows x 128 j-rows: 2 x 4 accumulator tiles of 32x32 (128 VGPRs);
-//   * per 32-haplotype K-step a lane holds 16 bits of "its" row (row = lane % 32, k-half = lane / 32) for
-//     2 A tiles (global loads: 32 consecutive rows of one chunk are 512 contiguous bytes) and 4 B tiles
-//     (ds_read_b128, two lanes per address), expands each 16 bits to 16 bytes
-//     (bfe, * 0x00204081, & 0x01010101) and issues 8 MFMAs;
-//   * A and B are expanded by the same function from the same bit positions, so whatever order the
+// Structure
+//   * 256-thread workgroups (4 waves), two per CU (<= 256 VGPRs, 36 KiB LDS each): one wave per SIMD and
+//     workgroup, so the partner on a SIMD belongs to the OTHER workgroup and drifts out of phase -- one
+//     runs its VALU epilogue while the other feeds the matrix pipe.
+//   * a wave's unit is 64 i-rows x 128 j-rows: 2 x 4 accumulator tiles of 32x32 (128 VGPRs); the four
+//     waves of a workgroup take four consecutive units of the same j-tile.
+//   * B side (the 128 j-rows, shared by the 4 waves): per 128-haplotype chunk the workgroup expands the
+//     j-tile's bits to bytes ONCE (each lane: 64 bits -> 4 x ds_write_b128) into a double-buffered LDS
+//     image [128 rows][144 B] (rows padded by 16 B: a 16-lane group of ds_read_b128 then hits 16 distinct
+//     16-byte slots); one barrier per chunk.  Fragments are plain ds_read_b128.
+//   * A side (a wave's own 64 rows): each lane loads the 16-byte chunk of "its" row (row = lane % 32 of
+//     each 32-row tile; 32 consecutive rows of a chunk are 512 contiguous bytes), three chunks deep in
+//     registers, and expands 16 bits per K-step in registers (bfe, * 0x00204081, & 0x01010101).
+//   * A and B are expanded from the same bit positions by the same arithmetic, so whatever order the
 //     hardware gives the 16 k-slots of a lane, slot s of A meets slot s of B: the sum over k is the
 //     AND-popcount.  Row/column placement follows the documented 32x32 C/D map
-//     (col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)), checked bit-exactly against
-//     the popcount kernel and the oracle in tests/.
+//     (col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)); tests compare every cell with
+//     the popcount kernel and the oracle.
+#include <stdlib.h>
+
 #include "ldx_common.h"
 #include "ldx_tile.h"
 
@@ -25,9 +33,11 @@ namespace ldx {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-constexpr int kMfmaWaves = 8;                 // 512 threads: two waves per SIMD at <= 256 VGPRs
+constexpr int kMfmaWaves = 4;
 constexpr int kMfmaThreads = kMfmaWaves * 64;
 constexpr uint32_t kRows64 = 64;              // i-rows per wave unit
+constexpr uint32_t kBRow = 144;               // bytes per expanded j-row in LDS (128 + 16 pad)
+constexpr uint32_t kBBuf = kSlab * kBRow;     // one buffer: 18 KiB
 
 // 16 haplotype bits (bits 0..15 of `bits`) -> 16 bytes of 0/1
 __device__ __forceinline__ v4i expand16(uint32_t bits)
@@ -45,20 +55,33 @@ __device__ __forceinline__ uint32_t word_of(const uint4 &v, int w)
     return w == 0 ? v.x : (w == 1 ? v.y : (w == 2 ? v.z : v.w));
 }
 
+// this thread's share of the j-tile expansion for one chunk: row = tid / 2, 64 haplotypes (tid % 2)
+__device__ __forceinline__ void expand_b_share(uint2 bits, unsigned char *buf, uint32_t tid)
+{
+    v4i *dst = reinterpret_cast<v4i *>(buf + (tid >> 1) * kBRow + (tid & 1u) * 64u);
+    dst[0] = expand16(bits.x);
+    dst[1] = expand16(bits.x >> 16);
+    dst[2] = expand16(bits.y);
+    dst[3] = expand16(bits.y >> 16);
+}
+
 template <bool kRaw, bool kN11>
-__global__ void __launch_bounds__(kMfmaThreads)
+__global__ void __launch_bounds__(kMfmaThreads, 2)
 triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ fa, const double *__restrict__ fr,
                      const double *__restrict__ q, uint32_t n_snps, uint32_t n_slabs, uint32_t nchunks, double n,
-                     uint64_t u_begin, uint64_t u_end, ldx_ld32 *__restrict__ out, ldx_ld64 *__restrict__ raw,
-                     uint32_t *__restrict__ n11)
+                     double rn, uint64_t u_begin, uint64_t u_end, ldx_ld32 *__restrict__ out, ldx_ld64 *__restrict__ raw,
+                     uint32_t *__restrict__ n11, int ablate)
 {
+    // `ablate` (env LDX_ABLATE, tuning only; 0 in production): 1 = no epilogue arithmetic, 2 = one chunk
+    // instead of all (no counting), 4 = no stores.  Results are wrong by design when it is non-zero.
     extern __shared__ uint4 lds[];
-    uint4 *jt = lds;
-    const uint32_t lane = threadIdx.x & 63u;
+    unsigned char *bexp = reinterpret_cast<unsigned char *>(lds);   // [2][128][144]
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
     const uint32_t l32 = lane & 31u;
     const uint32_t half = lane >> 5;
     const uint32_t sh = half * 16u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     // 64-row units: tile t owns groups g64 in [2t, 2T); unit v <-> small units [8v, 8v+8)
     const uint64_t G64 = (uint64_t)n_slabs * 2u;
@@ -79,27 +102,20 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
         t = lo;
     }
     uint64_t v = b0;
-    while (v < b1) {   // block-uniform trip count
+    while (v < b1) {   // block-uniform: every wave reaches every barrier
         const uint64_t tb = base64(t), te = base64(t + 1u);
         const uint64_t seg_end = b1 < te ? b1 : te;
-        const uint32_t seg_len = (uint32_t)(seg_end - v);
-        __syncthreads();
-        for (uint32_t k = threadIdx.x; k < nchunks * kSlab; k += kMfmaThreads)
-            jt[k] = alt[(size_t)t * nchunks * kSlab + k];
-        double fa2[4], fr2[4];
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-            fa2[tt] = fa[t * kSlab + 32u * tt + l32];
-            fr2[tt] = fr[t * kSlab + 32u * tt + l32];
-        }
-        __syncthreads();
+        // the j-tile's bits for this thread's expansion share: row tid/2, 8 bytes (tid%2) of each chunk
+        const uint2 *bsrc = reinterpret_cast<const uint2 *>(alt + (size_t)t * nchunks * kSlab) + tid;
 
-        for (uint32_t k = wave; k < seg_len; k += kMfmaWaves) {
-            const uint64_t vv = v + k;
-            const uint32_t g64 = (uint32_t)(vv - tb) + 2u * t;
+        for (uint64_t pass = v; pass < seg_end; pass += kMfmaWaves) {   // block-uniform
+            const uint64_t vv = pass + wave;
+            const bool active = vv < seg_end;
+            const uint32_t g64 = (uint32_t)((active ? vv : pass) - tb) + 2u * t;
             const uint32_t row0 = g64 * kRows64;
             // this lane's A rows: row0 + 32*m + l32 (both inside one slab: 64 | 128)
             const uint4 *ai = alt + ((size_t)(row0 / kSlab) * nchunks) * kSlab + (row0 % kSlab) + l32;
+
             v16i acc[2][4];
 #pragma unroll
             for (int m = 0; m < 2; ++m)
@@ -108,43 +124,124 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[m][tt][e] = 0;
 
-            uint4 a_raw[2], b_raw[4];
+            // ---- K loop, software-pipelined at K-step (32 haplotypes) granularity -------------------------
+            // During the 8 MFMAs of step s the wave (i) has the B fragments of step s+1 in flight from LDS,
+            // (ii) expands the A fragments of step s+1 and (iii) a quarter of its share of the NEXT chunk's
+            // B image.  One workgroup barrier per chunk, placed before the last K-step of the chunk: by then
+            // every wave has written its share of chunk c+1 (steps 0..1) and issued its last read of chunk c
+            // (the prefetch of step 3, done in step 2), so after it the fragments of (c+1, step 0) can be
+            // prefetched and the buffer of chunk c may be overwritten by chunk c+2.  sched_barrier(0) between
+            // steps keeps hipcc from hoisting a whole chunk's expansions ahead of the first MFMA.
+            auto read_bf = [&](v4i (&bf)[4], const unsigned char *buf, int w) {
 #pragma unroll
-            for (int m = 0; m < 2; ++m) a_raw[m] = ai[32 * m];
+                for (int tt = 0; tt < 4; ++tt)
+                    bf[tt] = *reinterpret_cast<const v4i *>(buf + (32u * tt + l32) * kBRow + w * 32u + half * 16u);
+            };
+            auto mma8 = [&](const v4i (&af)[2], const v4i (&bf)[4]) {
 #pragma unroll
-            for (int tt = 0; tt < 4; ++tt) b_raw[tt] = jt[32 * tt + l32];
-            for (uint32_t c = 0; c < nchunks; ++c) {
-                uint4 a_nxt[2], b_nxt[4];
-                const uint32_t cn = c + 1 < nchunks ? c + 1 : c;   // last prefetch re-reads a valid chunk
+                for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int m = 0; m < 2; ++m) a_nxt[m] = ai[(size_t)cn * kSlab + 32 * m];
+                    for (int tt = 0; tt < 4; ++tt)
+                        acc[m][tt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[m], bf[tt], acc[m][tt], 0, 0, 0);
+            };
+            auto interleave = [&]() {   // 8 x {1 MFMA, 5 VALU}: the VALU work of a step hides behind its MFMAs
 #pragma unroll
-                for (int tt = 0; tt < 4; ++tt) b_nxt[tt] = jt[cn * kSlab + 32 * tt + l32];
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    v4i af[2], bf[4];
-#pragma unroll
-                    for (int m = 0; m < 2; ++m) af[m] = expand16(word_of(a_raw[m], w) >> sh);
-#pragma unroll
-                    for (int tt = 0; tt < 4; ++tt) bf[tt] = expand16(word_of(b_raw[tt], w) >> sh);
-#pragma unroll
-                    for (int m = 0; m < 2; ++m)
-#pragma unroll
-                        for (int tt = 0; tt < 4; ++tt)
-                            acc[m][tt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[m], bf[tt], acc[m][tt], 0, 0, 0);
+                for (int k = 0; k < 8; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
                 }
-#pragma unroll
-                for (int m = 0; m < 2; ++m) a_raw[m] = a_nxt[m];
-#pragma unroll
-                for (int tt = 0; tt < 4; ++tt) b_raw[tt] = b_nxt[tt];
-            }
+            };
+            auto lds_barrier = [&]() {   // LDS-only barrier: no vmcnt(0), the global prefetches stay in flight
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            };
 
-            // epilogue: acc[m][tt][e] is pair (i, j) with
-            //   i = row0 + 32*m + (e & 3) + 8*(e >> 2) + 4*half,  j = 128*t + 32*tt + l32
+            __syncthreads();   // the previous pass has finished reading both buffers
+            expand_b_share(bsrc[0], bexp, tid);   // chunk 0 -> buffer 0
+            const uint32_t c1 = nchunks > 1 ? 1u : 0u;
+            uint4 a_cur[2], a_nxt[2];
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
+                a_cur[m] = ai[32 * m];
+                a_nxt[m] = ai[(size_t)c1 * kSlab + 32 * m];
+            }
+            uint2 b_bits = bsrc[(size_t)c1 * kSlab * 2u];   // bits of chunk 1 (expanded during chunk 0)
+            __syncthreads();
+            v4i af0[2], bf0[4], af1[2], bf1[4];
+            read_bf(bf0, bexp, 0);
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
+            for (int m = 0; m < 2; ++m) af0[m] = expand16(a_cur[m].x >> sh);
+
+            const uint32_t nch_run = (ablate & 2) ? 1u : nchunks;
+            for (uint32_t c = 0; c < nch_run; ++c) {
+                const unsigned char *rd = bexp + (c & 1u) * kBBuf;
+                unsigned char *wr = bexp + ((c + 1u) & 1u) * kBBuf;
+                v4i *bdst = reinterpret_cast<v4i *>(wr + (tid >> 1) * kBRow + (tid & 1u) * 64u);
+                const uint32_t c2 = c + 2 < nchunks ? c + 2 : nchunks - 1;   // clamped: surplus loads are discarded
+                // global prefetch for chunk c+2 (A rows, this thread's B bits); consumed one chunk later
+                uint4 a_far[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) a_far[m] = ai[(size_t)c2 * kSlab + 32 * m];
+                const uint2 b_far = bsrc[(size_t)c2 * kSlab * 2u];
+
+                // step 0: MFMAs of (c,0); prepare (c,1); B share: haplotypes 0..31 of this thread's 64
+                read_bf(bf1, rd, 1);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) af1[m] = expand16(a_cur[m].y >> sh);
+                bdst[0] = expand16(b_bits.x);
+                bdst[1] = expand16(b_bits.x >> 16);
+                mma8(af0, bf0);
+                interleave();
+                __builtin_amdgcn_sched_barrier(0);
+                // step 1: MFMAs of (c,1); prepare (c,2); B share: haplotypes 32..63
+                read_bf(bf0, rd, 2);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) af0[m] = expand16(a_cur[m].z >> sh);
+                bdst[2] = expand16(b_bits.y);
+                bdst[3] = expand16(b_bits.y >> 16);
+                mma8(af1, bf1);
+                interleave();
+                __builtin_amdgcn_sched_barrier(0);
+                // step 2: MFMAs of (c,2); prepare (c,3)
+                read_bf(bf1, rd, 3);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) af1[m] = expand16(a_cur[m].w >> sh);
+                mma8(af0, bf0);
+                interleave();
+                lds_barrier();   // chunk c+1 complete in `wr`; nobody reads `rd` any more
+                // step 3: MFMAs of (c,3); prepare (c+1,0) from the other buffer and the next A chunk
+                read_bf(bf0, wr, 0);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) af0[m] = expand16(a_nxt[m].x >> sh);
+                mma8(af1, bf1);
+                interleave();
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    a_cur[m] = a_nxt[m];
+                    a_nxt[m] = a_far[m];
+                }
+                b_bits = b_far;
+            }
+
+            if (!active) continue;   // wave-uniform; inactive waves only helped with B and the barriers
+            // epilogue: acc[m][tt][e] is pair (i, j) with
+            //   i = row0 + 32*m + (e & 3) + 8*(e >> 2) + 4*half,  j = 128*t + 32*tt + l32
+            double fa2[4], fr2[4];
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                fa2[tt] = fa[t * kSlab + 32u * tt + l32];
+                fr2[tt] = fr[t * kSlab + 32u * tt + l32];
+            }
+            // The e-loop is NOT unrolled: 128 pairs x ~90 instructions would be ~90 KB of straight-line code
+            // per wave, more than the instruction cache two CUs share.  acc[..][..][e] with a wave-uniform e
+            // is a register-indirect move (s_set_gpr_idx_on), not scratch.
+#pragma unroll 1
+            for (int e = 0; e < 16; ++e) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
                     const uint32_t ri = 32u * m + (e & 3) + 8u * (e >> 2) + 4u * half;   // row inside the unit
                     const uint32_t i = row0 + ri;
                     const double fa1 = fa[i], fr1 = fr[i], q1 = q[i];
@@ -158,13 +255,23 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                         const uint32_t cnt = (uint32_t)acc[m][tt][e];
                         ldx_ld32 res = {0.0f, 0.0f};
                         ldx_ld64 rw = {0.0, 0.0};
-                        if (valid) {
-                            const LdRaw lr = ld_epilogue((double)cnt / n, fa1, fr1, q1, fa2[tt], fr2[tt]);
-                            res = round_pair(lr);
-                            rw.r_square = lr.rsq;
-                            rw.d_prime = lr.dprime;
+                        if (ablate & 1) {
+                            res.r_square = (float)cnt;
+                        } else if (valid) {
+                            const double f11 = div_by_n((double)cnt, n, rn);   // calc_ld.py:33
+                            if (kRaw) {
+                                const LdRaw lr = ld_epilogue(f11, fa1, fr1, q1, fa2[tt], fr2[tt]);
+                                res = round_pair(lr);
+                                rw.r_square = lr.rsq;
+                                rw.d_prime = lr.dprime;
+                            } else {
+                                bool slow;
+                                res = ld_pair_fast(f11, fa1, fr1, q1, fa2[tt], fr2[tt], slow);
+                                if (__builtin_expect(__any(slow), 0))
+                                    if (slow) res = ld_pair_mirror(f11, fa1, fr1, q1, fa2[tt], fr2[tt]);
+                            }
                         }
-                        if (in_range) {
+                        if (in_range && !(ablate & 4)) {
                             const size_t o = (size_t)(us - u_begin) * LDX_UNIT_PAIRS + (size_t)(ri % kGroup) * kSlab + jl;
                             out[o] = res;
                             if (kRaw) raw[o] = rw;
@@ -185,22 +292,21 @@ static int launch_mfma(const void *alt, const double *fa, const double *fr, cons
                        uint32_t *out_n11, hipStream_t s)
 {
     const uint32_t nch = n_chunks(n_hap);
-    const size_t lds = (size_t)nch * kSlab * 16u;
-    LDX_HIP(hipFuncSetAttribute((const void *)triangle_mfma_kernel<kRaw, kN11>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const size_t lds = 2u * kBBuf;
     int dev = 0, cus = 256;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
         prop.multiProcessorCount > 0)
         cus = prop.multiProcessorCount;
     const uint64_t total = (unit_end + 7u) / 8u - unit_begin / 8u;
-    uint64_t grid = (uint64_t)cus;
+    uint64_t grid = 2u * (uint64_t)cus;   // persistent: two 4-wave workgroups per CU
     const uint64_t max_grid = (total + kMfmaWaves - 1) / kMfmaWaves;
     if (grid > max_grid) grid = max_grid;
     if (grid < 1) grid = 1;
     triangle_mfma_kernel<kRaw, kN11><<<(uint32_t)grid, kMfmaThreads, lds, s>>>(
-        (const uint4 *)alt, fa, fr, q, n_snps, n_slabs(n_snps), nch, (double)n_hap, unit_begin, unit_end, out, out_raw,
-        out_n11);
+        (const uint4 *)alt, fa, fr, q, n_snps, n_slabs(n_snps), nch, (double)n_hap, 1.0 / (double)n_hap, unit_begin,
+        unit_end, out, out_raw,
+        out_n11, getenv("LDX_ABLATE") ? atoi(getenv("LDX_ABLATE")) : 0);
     LDX_HIP(hipGetLastError());
     return LDX_OK;
 }

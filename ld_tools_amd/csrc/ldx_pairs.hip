@@ -33,7 +33,7 @@ template <bool kRaw, bool kN11>
 __global__ void __launch_bounds__(kThreads)
 triangle_kernel(const uint4 *__restrict__ alt, const double *__restrict__ fa, const double *__restrict__ fr,
                 const double *__restrict__ q, uint32_t n_snps, uint32_t n_slabs, uint32_t nchunks, double n,
-                uint64_t u_begin, uint64_t u_end, ldx_ld32 *__restrict__ out, ldx_ld64 *__restrict__ raw,
+                double rn, uint64_t u_begin, uint64_t u_end, ldx_ld32 *__restrict__ out, ldx_ld64 *__restrict__ raw,
                 uint32_t *__restrict__ n11)
 {
     extern __shared__ uint4 lds[];
@@ -82,11 +82,18 @@ triangle_kernel(const uint4 *__restrict__ alt, const double *__restrict__ fa, co
                     ldx_ld32 res = {0.0f, 0.0f};
                     ldx_ld64 rw = {0.0, 0.0};
                     if (valid) {
-                        const double f11 = (double)acc.v[r][jj] / n;   // calc_ld.py:33
-                        const LdRaw lr = ld_epilogue(f11, fa1, fr1, q1, fa2[jj], fr2[jj]);
-                        res = round_pair(lr);
-                        rw.r_square = lr.rsq;
-                        rw.d_prime = lr.dprime;
+                        const double f11 = div_by_n((double)acc.v[r][jj], n, rn);   // calc_ld.py:33
+                        if (kRaw) {   // parity / debugging output: the op-for-op mirror, unrounded values kept
+                            const LdRaw lr = ld_epilogue(f11, fa1, fr1, q1, fa2[jj], fr2[jj]);
+                            res = round_pair(lr);
+                            rw.r_square = lr.rsq;
+                            rw.d_prime = lr.dprime;
+                        } else {
+                            bool slow;
+                            res = ld_pair_fast(f11, fa1, fr1, q1, fa2[jj], fr2[jj], slow);
+                            if (__builtin_expect(__any(slow), 0))
+                                if (slow) res = ld_pair_mirror(f11, fa1, fr1, q1, fa2[jj], fr2[jj]);
+                        }
                     }
                     out[o] = res;
                     if (kRaw) raw[o] = rw;
@@ -130,7 +137,7 @@ pair_counts_kernel(const uint4 *__restrict__ alt_i, const uint4 *__restrict__ al
 }
 
 // ---- the epilogue alone, one element per thread ----
-__global__ void ld_from_counts_kernel(double n, size_t m, const uint32_t *__restrict__ n11,
+__global__ void ld_from_counts_kernel(double n, double rn, size_t m, const uint32_t *__restrict__ n11,
                                       const uint32_t *__restrict__ a1, const uint32_t *__restrict__ r1,
                                       const uint32_t *__restrict__ a2, const uint32_t *__restrict__ r2,
                                       ldx_ld64 *raw, ldx_ld32 *rounded, uint8_t *flags)
@@ -139,9 +146,18 @@ __global__ void ld_from_counts_kernel(double n, size_t m, const uint32_t *__rest
     if (k >= m) return;
     const double fa1 = (double)a1[k] / n, fr1 = (double)r1[k] / n;
     const double fa2 = (double)a2[k] / n, fr2 = (double)r2[k] / n;
+    // `raw` and `flags` come from the op-for-op mirror, `rounded` from the production path of the pair
+    // kernels (reciprocal division by n, fast epilogue, mirror fallback near ties) -- so the exhaustive
+    // small-n test pins exactly the code that ld_triangle / ld_area run.
+    const double f11 = div_by_n((double)n11[k], n, rn);
     const LdRaw lr = ld_epilogue((double)n11[k] / n, fa1, fr1, fa1 * fr1, fa2, fr2);
     if (raw) raw[k] = ldx_ld64{lr.rsq, lr.dprime};
-    if (rounded) rounded[k] = round_pair(lr);
+    if (rounded) {
+        bool slow;
+        ldx_ld32 res = ld_pair_fast(f11, fa1, fr1, fa1 * fr1, fa2, fr2, slow);
+        if (slow) res = ld_pair_mirror(f11, fa1, fr1, fa1 * fr1, fa2, fr2);
+        rounded[k] = res;
+    }
     if (flags) flags[k] = (uint8_t)lr.flags;
 }
 
@@ -245,8 +261,8 @@ static int launch_triangle(const void *alt, const double *fa, const double *fr, 
     const uint64_t max_grid = (total + kWaves - 1) / kWaves;   // at least one unit per wave
     if (grid > max_grid) grid = max_grid;
     triangle_kernel<kRaw, kN11><<<(uint32_t)grid, kThreads, lds, s>>>(
-        (const uint4 *)alt, fa, fr, q, n_snps, ldx::n_slabs(n_snps), nch, (double)n_hap, unit_begin, unit_end, out,
-        out_raw, out_n11);
+        (const uint4 *)alt, fa, fr, q, n_snps, ldx::n_slabs(n_snps), nch, (double)n_hap, 1.0 / (double)n_hap, unit_begin,
+        unit_end, out, out_raw, out_n11);
     LDX_HIP(hipGetLastError());
     return LDX_OK;
 }
@@ -259,6 +275,10 @@ extern "C" int ldx_triangle_dev(const void *alt, const double *fa, const double 
     LDX_REQUIRE(n_snps >= 1 && n_hap >= 1, "bad shape");
     if (n_hap > LDX_MAX_HAPS) {
         set_error("ldx_triangle_dev: n_hap %u > LDX_MAX_HAPS %u", n_hap, LDX_MAX_HAPS);
+        return LDX_E_UNSUPPORTED;
+    }
+    if (!check_recip(n_hap)) {
+        set_error("ldx_triangle_dev: reciprocal division check failed for n = %u", n_hap);
         return LDX_E_UNSUPPORTED;
     }
     const uint64_t U = ldx_triangle_units(n_snps);
@@ -308,8 +328,12 @@ extern "C" int ldx_ld_from_counts_dev(uint32_t n, size_t m, const uint32_t *n11,
     LDX_REQUIRE(n11 && a1 && r1 && a2 && r2, "null pointer");
     LDX_REQUIRE(n >= 1, "n must be positive (the reference raises ZeroDivisionError, calc_ld.py:33)");
     if (m == 0) return LDX_OK;
-    ld_from_counts_kernel<<<(uint32_t)((m + 255) / 256), 256, 0, (hipStream_t)stream>>>((double)n, m, n11, a1, r1, a2,
-                                                                                      r2, raw, rounded, flags);
+    if (!check_recip(n)) {
+        set_error("ldx_ld_from_counts_dev: reciprocal division check failed for n = %u", n);
+        return LDX_E_UNSUPPORTED;
+    }
+    ld_from_counts_kernel<<<(uint32_t)((m + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+        (double)n, 1.0 / (double)n, m, n11, a1, r1, a2, r2, raw, rounded, flags);
     LDX_HIP(hipGetLastError());
     return LDX_OK;
 }

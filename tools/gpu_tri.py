@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Time ld_triangle on a synthetic panel: python tools/gpu_tri.py <snps> <haps> <path> [reps]"""
+import json
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch  # noqa: E402
+
+from ld_tools_amd import PackedPanel, ld_triangle, ops, synth  # noqa: E402
+
+n, h, path = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+reps = int(sys.argv[4]) if len(sys.argv) > 4 else 5
+ops.set_triangle_path(path)
+p = PackedPanel.from_codes(synth.synth_codes_device(n, h))
+res = ld_triangle(p)
+torch.cuda.synchronize()
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+a.record()
+for _ in range(reps):
+    ld_triangle(p, out=res)
+b.record()
+torch.cuda.synchronize()
+ms = a.elapsed_time(b) / reps
+print(json.dumps({"snps": n, "haps": h, "path": path, "ms": ms, "pairs_per_s": p.n_pairs / (ms * 1e-3)}), flush=True)
