@@ -190,6 +190,12 @@ int ldx_calc_ld_host(const int8_t *g1, uint32_t h1, const int8_t *g2, uint32_t h
  * of 64, <= 1024), no memory traffic, and writes a checksum to sink[blocks*threads]. */
 int ldx_probe_andpop_dev(uint32_t *sink, uint32_t blocks, uint32_t threads, uint32_t iters, void *stream);
 
+/* Peak-rate probe for the matrix pipe: `iters` rounds of 8 back-to-back int8 MFMAs per wave on independent
+ * accumulators, operands in registers.  variant 0 = v_mfma_i32_32x32x32_i8 (32768 MACs each),
+ * 1 = v_mfma_i32_16x16x64_i8 (16384 MACs each).  threads <= 256. */
+int ldx_probe_mfma_dev(uint32_t *sink, uint32_t blocks, uint32_t threads, uint32_t iters, int variant,
+                       void *stream);
+
 #ifdef __cplusplus
 }
 #endif

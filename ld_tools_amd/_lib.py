@@ -7,11 +7,12 @@ the import raises -- there is no CPU path in this package.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 from . import build as _build
 
-LIB_PATH = Path(__file__).resolve().parent / "libldx.so"
+LIB_PATH = Path(os.environ.get("LDX_LIB") or Path(__file__).resolve().parent / "libldx.so")   # LDX_LIB: tuning variants
 
 # constants of include/ldx.h
 SLAB_ROWS = 128
@@ -97,6 +98,7 @@ SIGNATURES = {
     "ldx_synth_codes_dev": (_int, [_vp, _u32, _u32, _sz, _u64, _vp, _u64, _u32, _u64, _u32, _vp]),
     "ldx_calc_ld_host": (_int, [_vp, _u32, _vp, _u32, _vp, _vp, _vp, _vp, _vp]),
     "ldx_probe_andpop_dev": (_int, [_vp, _u32, _u32, _u32, _vp]),
+    "ldx_probe_mfma_dev": (_int, [_vp, _u32, _u32, _u32, _int, _vp]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

@@ -40,24 +40,30 @@ def stale() -> bool:
     return any(d.stat().st_mtime > t for d in deps)
 
 
-def build(force: bool = False, save_temps: bool = False, verbose: bool = True) -> Path:
-    if not force and not stale():
+def build(force: bool = False, save_temps: bool = False, verbose: bool = True, out: Path = LIB,
+          defines=()) -> Path:
+    """Build the library.  `out` / `defines` exist for tuning experiments (ablation variants of the
+    kernels selected with -DLDX_AB_...; loaded through the LDX_LIB environment variable)."""
+    if not force and not stale() and out == LIB:
         return LIB
-    tmp_lib = LIB.with_name(f"libldx.so.tmp.{os.getpid()}")
-    cmd = [hipcc(), *FLAGS, *[str(CSRC / s) for s in SOURCES], "-o", str(tmp_lib)]
+    tmp_lib = out.with_name(f"{out.name}.tmp.{os.getpid()}")
+    cmd = [hipcc(), *FLAGS, *defines, *[str(CSRC / s) for s in SOURCES], "-o", str(tmp_lib)]
     if save_temps:
         cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
     if verbose:
         print("[ldx build]", " ".join(cmd), file=sys.stderr)
     try:
         subprocess.run(cmd, check=True, cwd=str(PKG))
-        os.replace(tmp_lib, LIB)   # atomic: a concurrent loader sees the old or the new file, never half
+        os.replace(tmp_lib, out)   # atomic: a concurrent loader sees the old or the new file, never half
     finally:
         if tmp_lib.exists():
             tmp_lib.unlink()
-    return LIB
+    return out
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv)
-    print(LIB)
+    out = LIB
+    if "--out" in sys.argv:
+        out = PKG / sys.argv[sys.argv.index("--out") + 1]
+    print(build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv, out=out,
+                defines=[a for a in sys.argv[1:] if a.startswith("-D")]))

@@ -146,25 +146,29 @@ __device__ __forceinline__ ldx_ld32 ld_pair_fast(double f11, double fa1, double 
 {
     const double p = fa1 * fa2;
     const double d = f11 - p;
-    const double m1 = fa1 * fr2, m2 = fr1 * fa2;
-    const double dmax = m1 < m2 ? m1 : m2;
-    const double m3 = fr1 * fr2;
-    const double dmin = p < m3 ? p : m3;
+    const double dmax = __builtin_fmin(fa1 * fr2, fr1 * fa2);   // no NaNs here: fmin == the mirror's compare-select
+    const double dmin = __builtin_fmin(p, fr1 * fr2);
     const double bound = d >= 0.0 ? dmax : -dmin;            // signed like the mirror's
     const double den = (q1 * fa2) * fr2;
-    const bool degenerate = bound == 0.0;                    // monomorphic variant: both results are int 0
-    const double t = degenerate ? 1.0 : bound * den;         // bound != 0 implies all four frequencies != 0
+    // degenerate (a monomorphic variant): bound == 0 -> t == 0 -> r = inf -> y = NaN; NaN compares false
+    // below and the two results are replaced by the int-0 mark at the end, so no select is needed here.
+    // bound != 0 implies all four frequencies != 0, hence den != 0.
+    const bool degenerate = bound == 0.0;
+    const double t = bound * den;
     double r = __builtin_amdgcn_rcp(t);
     r = __builtin_fma(r, __builtin_fma(-t, r, 1.0), r);
     r = __builtin_fma(r, __builtin_fma(-t, r, 1.0), r);
-    const double yd = (d * (den * r)) * 1e4;                 // D' * 10^4   (den*r = 1/bound, sign included)
-    const double yr = ((d * d) * (bound * r)) * 1e4;         // r^2 * 10^4  (bound*r = 1/den > 0)
+    const double r4 = r * 1e4;
+    const double yd = d * (den * r4);                        // D' * 10^4   (den*r = 1/bound, sign included)
+    const double yr = (d * d) * (bound * r4);                // r^2 * 10^4  (bound*r = 1/den > 0)
     const double kd = __builtin_rint(yd), kr = __builtin_rint(yr);
-    const bool sure = __builtin_fabs(yd - kd) < 0.499999 && __builtin_fabs(yr - kr) < 0.499999 && yd < 1e9 && yr < 1e9;
-    slow = !degenerate && !sure;
+    const bool sure = __builtin_fabs(yd - kd) < 0.499999 && __builtin_fabs(yr - kr) < 0.499999 &&
+                      __builtin_fmax(yd, yr) < 1e9;
+    slow = !(sure || degenerate);
     ldx_ld32 o;
-    o.d_prime = encode32(degenerate ? 0.0 : kd, degenerate);
-    o.r_square = encode32(degenerate ? 0.0 : kr, degenerate || d == 0.0);   // d_prime == 0 <=> d == 0 here
+    const float vd = (float)(kd * 1e-4), vr = (float)(kr * 1e-4);   // float32 nearest to k / 10^4
+    o.d_prime = degenerate ? -0.0f : vd;
+    o.r_square = (degenerate || d == 0.0) ? -0.0f : vr;      // d_prime == 0 <=> d == 0 when bound != 0
     return o;
 }
 

@@ -50,6 +50,18 @@ __device__ __forceinline__ v4i expand16(uint32_t bits)
     return r;
 }
 
+// tuning-only build variants (python ld_tools_amd/build.py --out libldx_x.so -DLDX_AB_...; results are wrong)
+#ifdef LDX_AB_NOAEXP
+#define EXPAND_A(x) v4i{(int)(x), 1, 1, 1}
+#else
+#define EXPAND_A(x) expand16(x)
+#endif
+#ifdef LDX_AB_NOBEXP
+#define EXPAND_B(x) v4i{(int)(x), 1, 1, 1}
+#else
+#define EXPAND_B(x) expand16(x)
+#endif
+
 __device__ __forceinline__ uint32_t word_of(const uint4 &v, int w)
 {
     return w == 0 ? v.x : (w == 1 ? v.y : (w == 2 ? v.z : v.w));
@@ -91,6 +103,15 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
     const uint64_t b0 = v_begin + total * blockIdx.x / gridDim.x;
     const uint64_t b1 = v_begin + total * (blockIdx.x + 1) / gridDim.x;
     if (b0 >= b1) return;   // block-uniform
+
+    // Stagger: all workgroups do identical work, so the two that share a CU would run their K loops
+    // (matrix pipe) and their epilogues (VALU) at the same time and the pipes would take turns.  The
+    // second half of the grid (dispatched onto the CUs' second slots) starts half a period late, so one
+    // workgroup's epilogue runs beside the other's K loop.  Speed only; any placement is correct.
+    if ((ablate & 8) == 0 && blockIdx.x >= (gridDim.x + 1) / 2 && b1 - b0 >= 8) {
+        const uint32_t naps = nchunks / 4 + 8;   // ~ (nchunks * 1024 + 32k) / 2 cycles in naps of 64 * 32
+        for (uint32_t k = 0; k < naps; ++k) __builtin_amdgcn_s_sleep(32);
+    }
 
     uint32_t t;
     {
@@ -135,7 +156,11 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
             auto read_bf = [&](v4i (&bf)[4], const unsigned char *buf, int w) {
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt)
+#ifdef LDX_AB_NOBREAD
+                    bf[tt] = v4i{(int)(uintptr_t)buf + w + tt, 1, 1, 1};
+#else
                     bf[tt] = *reinterpret_cast<const v4i *>(buf + (32u * tt + l32) * kBRow + w * 32u + half * 16u);
+#endif
             };
             auto mma8 = [&](const v4i (&af)[2], const v4i (&bf)[4]) {
 #pragma unroll
@@ -153,8 +178,10 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
             };
             auto lds_barrier = [&]() {   // LDS-only barrier: no vmcnt(0), the global prefetches stay in flight
                 __builtin_amdgcn_sched_barrier(0);
+#ifndef LDX_AB_NOBARRIER
                 __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
                 __builtin_amdgcn_s_barrier();
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             };
 
@@ -172,7 +199,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
             v4i af0[2], bf0[4], af1[2], bf1[4];
             read_bf(bf0, bexp, 0);
 #pragma unroll
-            for (int m = 0; m < 2; ++m) af0[m] = expand16(a_cur[m].x >> sh);
+            for (int m = 0; m < 2; ++m) af0[m] = EXPAND_A(a_cur[m].x >> sh);
 
             const uint32_t nch_run = (ablate & 2) ? 1u : nchunks;
             for (uint32_t c = 0; c < nch_run; ++c) {
@@ -189,32 +216,32 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 // step 0: MFMAs of (c,0); prepare (c,1); B share: haplotypes 0..31 of this thread's 64
                 read_bf(bf1, rd, 1);
 #pragma unroll
-                for (int m = 0; m < 2; ++m) af1[m] = expand16(a_cur[m].y >> sh);
-                bdst[0] = expand16(b_bits.x);
-                bdst[1] = expand16(b_bits.x >> 16);
+                for (int m = 0; m < 2; ++m) af1[m] = EXPAND_A(a_cur[m].y >> sh);
+                bdst[0] = EXPAND_B(b_bits.x);
+                bdst[1] = EXPAND_B(b_bits.x >> 16);
                 mma8(af0, bf0);
                 interleave();
                 __builtin_amdgcn_sched_barrier(0);
                 // step 1: MFMAs of (c,1); prepare (c,2); B share: haplotypes 32..63
                 read_bf(bf0, rd, 2);
 #pragma unroll
-                for (int m = 0; m < 2; ++m) af0[m] = expand16(a_cur[m].z >> sh);
-                bdst[2] = expand16(b_bits.y);
-                bdst[3] = expand16(b_bits.y >> 16);
+                for (int m = 0; m < 2; ++m) af0[m] = EXPAND_A(a_cur[m].z >> sh);
+                bdst[2] = EXPAND_B(b_bits.y);
+                bdst[3] = EXPAND_B(b_bits.y >> 16);
                 mma8(af1, bf1);
                 interleave();
                 __builtin_amdgcn_sched_barrier(0);
                 // step 2: MFMAs of (c,2); prepare (c,3)
                 read_bf(bf1, rd, 3);
 #pragma unroll
-                for (int m = 0; m < 2; ++m) af1[m] = expand16(a_cur[m].w >> sh);
+                for (int m = 0; m < 2; ++m) af1[m] = EXPAND_A(a_cur[m].w >> sh);
                 mma8(af0, bf0);
                 interleave();
                 lds_barrier();   // chunk c+1 complete in `wr`; nobody reads `rd` any more
                 // step 3: MFMAs of (c,3); prepare (c+1,0) from the other buffer and the next A chunk
                 read_bf(bf0, wr, 0);
 #pragma unroll
-                for (int m = 0; m < 2; ++m) af0[m] = expand16(a_nxt[m].x >> sh);
+                for (int m = 0; m < 2; ++m) af0[m] = EXPAND_A(a_nxt[m].x >> sh);
                 mma8(af1, bf1);
                 interleave();
                 __builtin_amdgcn_sched_barrier(0);
@@ -235,6 +262,9 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 fa2[tt] = fa[t * kSlab + 32u * tt + l32];
                 fr2[tt] = fr[t * kSlab + 32u * tt + l32];
             }
+            // one coalesced load per statistic for the unit's 64 rows (instead of a dependent global load per
+            // row inside the loop: 32 exposed latencies per unit)
+            const double sfa = fa[row0 + lane], sfr = fr[row0 + lane], sq = q[row0 + lane];
             // The e-loop is NOT unrolled: 128 pairs x ~90 instructions would be ~90 KB of straight-line code
             // per wave, more than the instruction cache two CUs share.  acc[..][..][e] with a wave-uniform e
             // is a register-indirect move (s_set_gpr_idx_on), not scratch.
@@ -244,7 +274,8 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 for (int m = 0; m < 2; ++m) {
                     const uint32_t ri = 32u * m + (e & 3) + 8u * (e >> 2) + 4u * half;   // row inside the unit
                     const uint32_t i = row0 + ri;
-                    const double fa1 = fa[i], fr1 = fr[i], q1 = q[i];
+                    // lane L preloaded the statistics of row row0 + L: fetch row ri's through the LDS crossbar
+                    const double fa1 = __shfl(sfa, (int)ri), fr1 = __shfl(sfr, (int)ri), q1 = __shfl(sq, (int)ri);
                     const uint64_t us = vv * 8u + ri / kGroup;   // the small unit this row belongs to
                     const bool in_range = us >= u_begin && us < u_end;
 #pragma unroll
@@ -325,3 +356,56 @@ int triangle_mfma(const void *alt, const double *fa, const double *fr, const dou
 }
 
 }  // namespace ldx
+
+// ---- peak-rate probe for the matrix pipe: back-to-back int8 MFMAs on 8 independent accumulators,
+// operands in registers, no memory traffic.  variant 0: 32x32x32 (32 K MACs), 1: 16x16x64 (16 K MACs).
+namespace ldx {
+typedef int v4i_p __attribute__((ext_vector_type(4)));
+typedef int v16i_p __attribute__((ext_vector_type(16)));
+template <int kVariant>
+__global__ void __launch_bounds__(256) probe_mfma_kernel(uint32_t *__restrict__ sink, uint32_t iters)
+{
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    v4i_p a = {(int)(tid & 0x01010101u), 0x01000100, 0x00010001, 0x01010000};
+    v4i_p b = {0x01010101, (int)((tid >> 3) & 0x01010101u), 0x00000101, 0x01000001};
+    uint32_t s = 0;
+    if (kVariant == 0) {
+        v16i_p acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[k][e] = 0;
+        for (uint32_t it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc[k], 0, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s += (uint32_t)acc[k][e];
+    } else {
+        v4i_p acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = v4i_p{0, 0, 0, 0};
+        for (uint32_t it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc[k], 0, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += (uint32_t)(acc[k].x + acc[k].y + acc[k].z + acc[k].w);
+    }
+    sink[tid] = s;
+}
+}  // namespace ldx
+
+extern "C" int ldx_probe_mfma_dev(uint32_t *sink, uint32_t blocks, uint32_t threads, uint32_t iters, int variant,
+                                  void *stream)
+{
+    LDX_REQUIRE(sink && blocks >= 1 && threads >= 64 && threads <= 256 && threads % 64 == 0, "bad argument");
+    if (variant == 0)
+        ldx::probe_mfma_kernel<0><<<blocks, threads, 0, (hipStream_t)stream>>>(sink, iters);
+    else
+        ldx::probe_mfma_kernel<1><<<blocks, threads, 0, (hipStream_t)stream>>>(sink, iters);
+    LDX_HIP(hipGetLastError());
+    return LDX_OK;
+}
