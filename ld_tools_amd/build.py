@@ -48,12 +48,15 @@ def build(force: bool = False, save_temps: bool = False, verbose: bool = True, o
         return LIB
     tmp_lib = out.with_name(f"{out.name}.tmp.{os.getpid()}")
     cmd = [hipcc(), *FLAGS, *defines, *[str(CSRC / s) for s in SOURCES], "-o", str(tmp_lib)]
-    if save_temps:
-        cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
+    cwd = PKG
+    if save_temps:   # the .s / .bc files land in ld_tools_amd/build/ (git-ignored)
+        cwd = PKG / "build"
+        cwd.mkdir(exist_ok=True)
+        cmd += ["-save-temps=cwd", "-Rpass-analysis=kernel-resource-usage"]
     if verbose:
         print("[ldx build]", " ".join(cmd), file=sys.stderr)
     try:
-        subprocess.run(cmd, check=True, cwd=str(PKG))
+        subprocess.run(cmd, check=True, cwd=str(cwd))
         os.replace(tmp_lib, out)   # atomic: a concurrent loader sees the old or the new file, never half
     finally:
         if tmp_lib.exists():

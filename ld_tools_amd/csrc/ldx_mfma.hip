@@ -33,7 +33,10 @@ namespace ldx {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-constexpr int kMfmaWaves = 4;
+#ifndef LDX_MFMA_WAVES
+#define LDX_MFMA_WAVES 4   // waves per workgroup: 4 (two workgroups per CU) or 8 (one per CU, B shared 8 ways)
+#endif
+constexpr int kMfmaWaves = LDX_MFMA_WAVES;
 constexpr int kMfmaThreads = kMfmaWaves * 64;
 constexpr uint32_t kRows64 = 64;              // i-rows per wave unit
 constexpr uint32_t kBRow = 144;               // bytes per expanded j-row in LDS (128 + 16 pad)
@@ -82,8 +85,13 @@ __global__ void __launch_bounds__(kMfmaThreads, 2)
 triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ fa, const double *__restrict__ fr,
                      const double *__restrict__ q, uint32_t n_snps, uint32_t n_slabs, uint32_t nchunks, double n,
                      double rn, uint64_t u_begin, uint64_t u_end, ldx_ld32 *__restrict__ out, ldx_ld64 *__restrict__ raw,
-                     uint32_t *__restrict__ n11, int ablate)
+                     uint32_t *__restrict__ n11, int ablate_arg)
 {
+    // experiment 64: workgroups of the first half of the grid run the K loop only, the others the epilogue
+    // only (do the two phases overlap when they sit on the same SIMD?); 128: only the first half works
+    int ablate = ablate_arg;
+    if (ablate_arg & 64) ablate = (blockIdx.x < (gridDim.x + 1) / 2) ? (5 | 8) : (2 | 8);
+    if ((ablate_arg & 128) && blockIdx.x >= (gridDim.x + 1) / 2) return;
     // `ablate` (env LDX_ABLATE, tuning only; 0 in production): 1 = no epilogue arithmetic, 2 = one chunk
     // instead of all (no counting), 4 = no stores.  Results are wrong by design when it is non-zero.
     extern __shared__ uint4 lds[];
@@ -108,7 +116,9 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
     // (matrix pipe) and their epilogues (VALU) at the same time and the pipes would take turns.  The
     // second half of the grid (dispatched onto the CUs' second slots) starts half a period late, so one
     // workgroup's epilogue runs beside the other's K loop.  Speed only; any placement is correct.
-    if ((ablate & 8) == 0 && blockIdx.x >= (gridDim.x + 1) / 2 && b1 - b0 >= 8) {
+    const bool late = (ablate & 16) ? (blockIdx.x & 1u) != 0 : ((ablate & 32) ? ((blockIdx.x >> 3) & 1u) != 0
+                                                                              : blockIdx.x >= (gridDim.x + 1) / 2);
+    if ((ablate & 8) == 0 && late && b1 - b0 >= 8) {
         const uint32_t naps = nchunks / 4 + 8;   // ~ (nchunks * 1024 + 32k) / 2 cycles in naps of 64 * 32
         for (uint32_t k = 0; k < naps; ++k) __builtin_amdgcn_s_sleep(32);
     }
@@ -127,7 +137,16 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
         const uint64_t tb = base64(t), te = base64(t + 1u);
         const uint64_t seg_end = b1 < te ? b1 : te;
         // the j-tile's bits for this thread's expansion share: row tid/2, 8 bytes (tid%2) of each chunk
+#if LDX_MFMA_WAVES == 8
+        // 512 threads: row tid/4, one 32-bit word (tid%4) of each chunk
+        const uint32_t *bsrc = reinterpret_cast<const uint32_t *>(alt + (size_t)t * nchunks * kSlab) + tid;
+        constexpr uint32_t kBStride = kSlab * 4u;   // words per chunk
+        const uint32_t b_off = (tid >> 2) * kBRow + (tid & 3u) * 32u;
+#else
         const uint2 *bsrc = reinterpret_cast<const uint2 *>(alt + (size_t)t * nchunks * kSlab) + tid;
+        constexpr uint32_t kBStride = kSlab * 2u;   // uint2 per chunk
+        const uint32_t b_off = (tid >> 1) * kBRow + (tid & 1u) * 64u;
+#endif
 
         for (uint64_t pass = v; pass < seg_end; pass += kMfmaWaves) {   // block-uniform
             const uint64_t vv = pass + wave;
@@ -170,6 +189,10 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                         acc[m][tt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[m], bf[tt], acc[m][tt], 0, 0, 0);
             };
             auto interleave = [&]() {   // 8 x {1 MFMA, 5 VALU}: the VALU work of a step hides behind its MFMAs
+                // the next step's four B-fragment reads go FIRST: a whole step (256 cycles) of cover for the LDS
+                // latency; left to itself hipcc sinks them to the end of the step and the next step's first
+                // MFMAs wait on lgkmcnt
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -186,72 +209,98 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
             };
 
             __syncthreads();   // the previous pass has finished reading both buffers
-            expand_b_share(bsrc[0], bexp, tid);   // chunk 0 -> buffer 0
-            const uint32_t c1 = nchunks > 1 ? 1u : 0u;
-            uint4 a_cur[2], a_nxt[2];
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                a_cur[m] = ai[32 * m];
-                a_nxt[m] = ai[(size_t)c1 * kSlab + 32 * m];
+            {   // chunk 0 -> buffer 0
+                v4i *d0 = reinterpret_cast<v4i *>(bexp + b_off);
+#if LDX_MFMA_WAVES == 8
+                const uint32_t w0 = bsrc[0];
+                d0[0] = expand16(w0);
+                d0[1] = expand16(w0 >> 16);
+#else
+                const uint2 w0 = bsrc[0];
+                d0[0] = expand16(w0.x);
+                d0[1] = expand16(w0.x >> 16);
+                d0[2] = expand16(w0.y);
+                d0[3] = expand16(w0.y >> 16);
+#endif
             }
-            uint2 b_bits = bsrc[(size_t)c1 * kSlab * 2u];   // bits of chunk 1 (expanded during chunk 0)
+            // Global prefetch ring, 3 chunks deep, statically indexed (the chunk loop is unrolled by 3 so no
+            // register is ever MOVED: a move of a register with a load in flight is a wait).  During chunk c
+            // the loads of chunk c+2 are issued; the A words are first touched at the end of chunk c+1 (the j
+            // bits, re-read by every pass of the tile and therefore cache-hot, at its start).  With one chunk of
+            // cover the K loop ran at the latency of those loads (~1900 cycles per chunk, matrix pipe 47 % busy
+            // for a lone wave) instead of at the 1024 cycles of its 32 MFMAs.
+            auto clampc = [&](uint32_t c) { return c < nchunks ? c : nchunks - 1u; };   // surplus loads are discarded
+            uint4 ar[3][2];
+            decltype(bsrc[0] + 0) br[3];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                br[k] = bsrc[(size_t)clampc(k) * kBStride];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) ar[k][m] = ai[(size_t)clampc(k) * kSlab + 32 * m];
+            }
             __syncthreads();
             v4i af0[2], bf0[4], af1[2], bf1[4];
             read_bf(bf0, bexp, 0);
 #pragma unroll
-            for (int m = 0; m < 2; ++m) af0[m] = EXPAND_A(a_cur[m].x >> sh);
+            for (int m = 0; m < 2; ++m) af0[m] = EXPAND_A(ar[0][m].x >> sh);
 
             const uint32_t nch_run = (ablate & 2) ? 1u : nchunks;
-            for (uint32_t c = 0; c < nch_run; ++c) {
-                const unsigned char *rd = bexp + (c & 1u) * kBBuf;
-                unsigned char *wr = bexp + ((c + 1u) & 1u) * kBBuf;
-                v4i *bdst = reinterpret_cast<v4i *>(wr + (tid >> 1) * kBRow + (tid & 1u) * 64u);
-                const uint32_t c2 = c + 2 < nchunks ? c + 2 : nchunks - 1;   // clamped: surplus loads are discarded
-                // global prefetch for chunk c+2 (A rows, this thread's B bits); consumed one chunk later
-                uint4 a_far[2];
-#pragma unroll
-                for (int m = 0; m < 2; ++m) a_far[m] = ai[(size_t)c2 * kSlab + 32 * m];
-                const uint2 b_far = bsrc[(size_t)c2 * kSlab * 2u];
-
-                // step 0: MFMAs of (c,0); prepare (c,1); B share: haplotypes 0..31 of this thread's 64
-                read_bf(bf1, rd, 1);
-#pragma unroll
-                for (int m = 0; m < 2; ++m) af1[m] = EXPAND_A(a_cur[m].y >> sh);
-                bdst[0] = EXPAND_B(b_bits.x);
-                bdst[1] = EXPAND_B(b_bits.x >> 16);
-                mma8(af0, bf0);
-                interleave();
-                __builtin_amdgcn_sched_barrier(0);
-                // step 1: MFMAs of (c,1); prepare (c,2); B share: haplotypes 32..63
-                read_bf(bf0, rd, 2);
-#pragma unroll
-                for (int m = 0; m < 2; ++m) af0[m] = EXPAND_A(a_cur[m].z >> sh);
-                bdst[2] = EXPAND_B(b_bits.y);
-                bdst[3] = EXPAND_B(b_bits.y >> 16);
-                mma8(af1, bf1);
-                interleave();
-                __builtin_amdgcn_sched_barrier(0);
-                // step 2: MFMAs of (c,2); prepare (c,3)
-                read_bf(bf1, rd, 3);
-#pragma unroll
-                for (int m = 0; m < 2; ++m) af1[m] = EXPAND_A(a_cur[m].w >> sh);
-                mma8(af0, bf0);
-                interleave();
-                lds_barrier();   // chunk c+1 complete in `wr`; nobody reads `rd` any more
-                // step 3: MFMAs of (c,3); prepare (c+1,0) from the other buffer and the next A chunk
-                read_bf(bf0, wr, 0);
-#pragma unroll
-                for (int m = 0; m < 2; ++m) af0[m] = EXPAND_A(a_nxt[m].x >> sh);
-                mma8(af1, bf1);
-                interleave();
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    a_cur[m] = a_nxt[m];
-                    a_nxt[m] = a_far[m];
-                }
-                b_bits = b_far;
+            // one chunk: ring slot CUR holds its A words, slot NXT the next chunk's (A words and B bits),
+            // slot FAR receives chunk c+2
+#define LDX_CHUNK(CUR, NXT, FAR, cc)                                                                               \
+            {                                                                                                      \
+                const uint32_t c_ = (cc);                                                                          \
+                const unsigned char *rd = bexp + (c_ & 1u) * kBBuf;                                                \
+                unsigned char *wr = bexp + ((c_ + 1u) & 1u) * kBBuf;                                               \
+                v4i *bdst = reinterpret_cast<v4i *>(wr + b_off);                                                   \
+                const uint32_t c3 = clampc(c_ + 2u);                                                               \
+                /* B bits FIRST: vmcnt counts in order, so waiting for them (next chunk, step 0) must not */      \
+                /* also wait for this batch's A words (needed only at the end of the next chunk) */               \
+                br[FAR] = bsrc[(size_t)c3 * kBStride];                                                             \
+                __builtin_amdgcn_sched_barrier(0);                                                                 \
+                _Pragma("unroll") for (int m = 0; m < 2; ++m) ar[FAR][m] = ai[(size_t)c3 * kSlab + 32 * m];        \
+                /* step 0: MFMAs of (c,0); prepare (c,1); first half of this thread's share of B chunk c+1 */     \
+                read_bf(bf1, rd, 1);                                                                               \
+                _Pragma("unroll") for (int m = 0; m < 2; ++m) af1[m] = EXPAND_A(ar[CUR][m].y >> sh);               \
+                LDX_BSHARE_0(br[NXT]);                                                                             \
+                mma8(af0, bf0);                                                                                    \
+                interleave();                                                                                      \
+                __builtin_amdgcn_sched_barrier(0);                                                                 \
+                /* step 1: MFMAs of (c,1); prepare (c,2); second half of the B share */                           \
+                read_bf(bf0, rd, 2);                                                                               \
+                _Pragma("unroll") for (int m = 0; m < 2; ++m) af0[m] = EXPAND_A(ar[CUR][m].z >> sh);               \
+                LDX_BSHARE_1(br[NXT]);                                                                             \
+                mma8(af1, bf1);                                                                                    \
+                interleave();                                                                                      \
+                __builtin_amdgcn_sched_barrier(0);                                                                 \
+                /* step 2: MFMAs of (c,2); prepare (c,3) */                                                       \
+                read_bf(bf1, rd, 3);                                                                               \
+                _Pragma("unroll") for (int m = 0; m < 2; ++m) af1[m] = EXPAND_A(ar[CUR][m].w >> sh);               \
+                mma8(af0, bf0);                                                                                    \
+                interleave();                                                                                      \
+                lds_barrier(); /* chunk c+1 complete in `wr`; nobody reads `rd` any more */                       \
+                /* step 3: MFMAs of (c,3); prepare (c+1,0) from the other buffer and the next A chunk */          \
+                read_bf(bf0, wr, 0);                                                                               \
+                _Pragma("unroll") for (int m = 0; m < 2; ++m) af0[m] = EXPAND_A(ar[NXT][m].x >> sh);               \
+                mma8(af1, bf1);                                                                                    \
+                interleave();                                                                                      \
+                __builtin_amdgcn_sched_barrier(0);                                                                 \
             }
+#if LDX_MFMA_WAVES == 8
+#define LDX_BSHARE_0(bits) bdst[0] = EXPAND_B(bits)
+#define LDX_BSHARE_1(bits) bdst[1] = EXPAND_B((bits) >> 16)
+#else
+#define LDX_BSHARE_0(bits) bdst[0] = EXPAND_B((bits).x); bdst[1] = EXPAND_B((bits).x >> 16)
+#define LDX_BSHARE_1(bits) bdst[2] = EXPAND_B((bits).y); bdst[3] = EXPAND_B((bits).y >> 16)
+#endif
+            for (uint32_t c = 0; c < nch_run; c += 3) {   // block-uniform guards: every wave reaches every barrier
+                LDX_CHUNK(0, 1, 2, c)
+                if (c + 1 < nch_run) LDX_CHUNK(1, 2, 0, c + 1)
+                if (c + 2 < nch_run) LDX_CHUNK(2, 0, 1, c + 2)
+            }
+#undef LDX_CHUNK
+#undef LDX_BSHARE_0
+#undef LDX_BSHARE_1
 
             if (!active) continue;   // wave-uniform; inactive waves only helped with B and the barriers
             // epilogue: acc[m][tt][e] is pair (i, j) with
@@ -278,35 +327,53 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                     const double fa1 = __shfl(sfa, (int)ri), fr1 = __shfl(sfr, (int)ri), q1 = __shfl(sq, (int)ri);
                     const uint64_t us = vv * 8u + ri / kGroup;   // the small unit this row belongs to
                     const bool in_range = us >= u_begin && us < u_end;
+                    // The four pairs of this row (one per column tile) go through the fast epilogue WITHOUT
+                    // branches -- invalid cells (row <= col, pad rows) are computed on whatever the registers
+                    // hold and zeroed by a select -- so their four dependent fp64 chains interleave; with a
+                    // branch per pair a lone wave spent 545 cycles per pair on a 50-instruction epilogue.
+                    uint32_t cnt[4];
+                    double f11[4];
+                    ldx_ld32 res[4];
+                    ldx_ld64 rw[4];
+                    bool valid[4], slow[4];
+                    bool any_slow = false;
 #pragma unroll
                     for (int tt = 0; tt < 4; ++tt) {
-                        const uint32_t jl = 32u * tt + l32;
-                        const uint32_t j = t * kSlab + jl;
-                        const bool valid = (i > j) && (i < n_snps);
-                        const uint32_t cnt = (uint32_t)acc[m][tt][e];
-                        ldx_ld32 res = {0.0f, 0.0f};
-                        ldx_ld64 rw = {0.0, 0.0};
-                        if (ablate & 1) {
-                            res.r_square = (float)cnt;
-                        } else if (valid) {
-                            const double f11 = div_by_n((double)cnt, n, rn);   // calc_ld.py:33
-                            if (kRaw) {
-                                const LdRaw lr = ld_epilogue(f11, fa1, fr1, q1, fa2[tt], fr2[tt]);
-                                res = round_pair(lr);
-                                rw.r_square = lr.rsq;
-                                rw.d_prime = lr.dprime;
-                            } else {
-                                bool slow;
-                                res = ld_pair_fast(f11, fa1, fr1, q1, fa2[tt], fr2[tt], slow);
-                                if (__builtin_expect(__any(slow), 0))
-                                    if (slow) res = ld_pair_mirror(f11, fa1, fr1, q1, fa2[tt], fr2[tt]);
-                            }
+                        const uint32_t j = t * kSlab + 32u * tt + l32;
+                        valid[tt] = (i > j) && (i < n_snps);
+                        cnt[tt] = (uint32_t)acc[m][tt][e];
+                        f11[tt] = div_by_n((double)cnt[tt], n, rn);   // calc_ld.py:33
+                        rw[tt] = ldx_ld64{0.0, 0.0};
+                        if (ablate & 1) {   // tuning: no epilogue arithmetic
+                            res[tt] = ldx_ld32{(float)cnt[tt], 0.0f};
+                            slow[tt] = false;
+                        } else if (kRaw) {   // parity / debugging output: the op-for-op mirror, unrounded values kept
+                            const LdRaw lr = ld_epilogue(f11[tt], fa1, fr1, q1, fa2[tt], fr2[tt]);
+                            res[tt] = round_pair(lr);
+                            if (valid[tt]) rw[tt] = ldx_ld64{lr.rsq, lr.dprime};
+                            slow[tt] = false;
+                        } else {
+                            res[tt] = ld_pair_fast(f11[tt], fa1, fr1, q1, fa2[tt], fr2[tt], slow[tt]);
+                            slow[tt] = slow[tt] && valid[tt];
+                            any_slow = any_slow || slow[tt];
                         }
-                        if (in_range && !(ablate & 4)) {
+                    }
+                    if (!kRaw && __builtin_expect(__any(any_slow), 0)) {   // near a rounding tie: the exact mirror
+#pragma unroll
+                        for (int tt = 0; tt < 4; ++tt)
+                            if (slow[tt]) res[tt] = ld_pair_mirror(f11[tt], fa1, fr1, q1, fa2[tt], fr2[tt]);
+                    }
+                    if (in_range && !(ablate & 4)) {
+#pragma unroll
+                        for (int tt = 0; tt < 4; ++tt) {
+                            const uint32_t jl = 32u * tt + l32;
                             const size_t o = (size_t)(us - u_begin) * LDX_UNIT_PAIRS + (size_t)(ri % kGroup) * kSlab + jl;
-                            out[o] = res;
-                            if (kRaw) raw[o] = rw;
-                            if (kN11) n11[o] = valid ? cnt : 0u;
+                            ldx_ld32 w = res[tt];
+                            if (!valid[tt]) w = ldx_ld32{0.0f, 0.0f};
+                            if (ablate & 1) w.r_square = (float)cnt[tt];
+                            out[o] = w;
+                            if (kRaw) raw[o] = rw[tt];
+                            if (kN11) n11[o] = valid[tt] ? cnt[tt] : 0u;
                         }
                     }
                 }
@@ -330,7 +397,7 @@ static int launch_mfma(const void *alt, const double *fa, const double *fr, cons
         prop.multiProcessorCount > 0)
         cus = prop.multiProcessorCount;
     const uint64_t total = (unit_end + 7u) / 8u - unit_begin / 8u;
-    uint64_t grid = 2u * (uint64_t)cus;   // persistent: two 4-wave workgroups per CU
+    uint64_t grid = (uint64_t)cus * (8u / kMfmaWaves);   // persistent: 8 waves per CU (two 4-wave workgroups or one of 8)
     const uint64_t max_grid = (total + kMfmaWaves - 1) / kMfmaWaves;
     if (grid > max_grid) grid = max_grid;
     if (grid < 1) grid = 1;
