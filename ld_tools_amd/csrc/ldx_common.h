@@ -172,4 +172,88 @@ __device__ __forceinline__ ldx_ld32 ld_pair_fast(double f11, double fa1, double 
     return o;
 }
 
+// ---- count-domain fast epilogue (used by the fused pair kernels for the 8-byte/pair output) ---------------
+// Same contract as ld_pair_fast -- k = round(x, 4) * 10^4 and the int-0 marks of the mirror, or `slow` -- but
+// computed from the EXACT integer  Dn = n*n11 - a1*a2  (d = Dn / n^2) and per-SNP reciprocals, so a pair costs
+// ~33 VALU instructions with no division, no reciprocal instruction and no Newton step:
+//     D'  * 10^4 = 10^4 |Dn| / B,   B = Dn >= 0 ? min(a1 r2, r1 a2) : min(a1 a2, r1 r2)   (calc_ld.py:63-76)
+//                                   1/B = max of the two products of per-SNP reciprocals
+//     r^2 * 10^4 = 10^4 Dn^2 / (a1 r1 a2 r2)                                              (calc_ld.py:86-88)
+// Why this may replace the op-for-op mirror: the reference's own value differs from the exact rational one by
+// its rounding errors, dominated by the cancellation in d = f11 - fa1*fa2 (|delta d| <= 4.5e-16: f11 and the
+// product are each rounded below 1).  In units of y = value * 10^4 that is  delta_d * n^2 * 10^4 / B  for D' and
+// 2 * delta_d * n^2 * y_r / |Dn|  for r^2; every other rounding (ours and the reference's) is < 1e-8 for
+// y < 1e7.  So when y is farther from a half-integer than 1e-6 + that bound, both round to the same k.  Pairs
+// that are not `sure` -- exact ties such as D' = 27/32, tiny |Dn| with tiny B, Dn == 0 (the reference's d may be
+// a rounding residue instead of 0 and that decides its int-0 mark), y >= 1e7 -- are recomputed by the caller
+// with ld_pair_mirror.  Degenerate pairs (a count of 0: both of the reference's bounds are 0, calc_ld.py:68-69,
+// 75-76, 89-90) have 1/B = inf and get the int-0 marks directly.
+struct FastRow {   // per var_1 (row / query):  1e4 * a,  1/a,  1/r,  1e-4 / (a r)
+    double a_s, ra, rr, rq_s;
+};
+struct FastCol {   // per var_2 (column / opposing):  a,  1/a,  1/r,  1 / (a r)
+    double a, ra, rr, rq;
+};
+struct FastConst {   // per launch
+    double nsc;      // 1e4 * n / count_scale   (count_scale = 8 on the MFMA path: its accumulators hold 8 * n11)
+    double cd, cr;   // margins per unit of 1/B and of |z| (see fast_const)
+};
+
+__host__ __device__ inline FastConst fast_const(double n, double count_scale)
+{
+    FastConst c;
+    c.nsc = 1e4 * n / count_scale;   // exact: count_scale is 1 or 8 and n < 2^32
+    c.cd = 6e-12 * n * n;            // >= 1e4 * 4.5e-16 * n^2, with a third to spare
+    c.cr = 2.0 * c.cd;
+    return c;
+}
+
+__device__ __forceinline__ FastRow fast_row(double fa, double fr, double n)
+{
+    const double a = __builtin_rint(fa * n), r = __builtin_rint(fr * n);   // the counts back from a/n, r/n: exact
+    FastRow o;
+    o.a_s = 1e4 * a;
+    o.ra = 1.0 / a;   // inf for a count of 0
+    o.rr = 1.0 / r;
+    o.rq_s = 1e-4 * (o.ra * o.rr);
+    return o;
+}
+
+__device__ __forceinline__ FastCol fast_col(double fa, double fr, double n)
+{
+    const double a = __builtin_rint(fa * n), r = __builtin_rint(fr * n);
+    FastCol o;
+    o.a = a;
+    o.ra = 1.0 / a;
+    o.rr = 1.0 / r;
+    o.rq = o.ra * o.rr;
+    return o;
+}
+
+// cnt_scaled = count_scale * n11 as a double
+__device__ __forceinline__ ldx_ld32 ld_pair_fast2(double cnt_scaled, const FastConst &k, double a1s, double ra1,
+                                                  double rr1, double rq1s, double a2, double ra2, double rr2,
+                                                  double rq2, bool &slow)
+{
+    const double dn4 = __builtin_fma(cnt_scaled, k.nsc, -(a1s * a2));   // 1e4 * Dn, exact (< 2^53)
+    const bool neg = dn4 < 0.0;
+    const double x = neg ? ra2 : rr2, y = neg ? rr2 : ra2;
+    const double inv = __builtin_fmax(ra1 * x, rr1 * y);                 // 1 / B  (inf: degenerate)
+    const double yd = __builtin_fabs(dn4) * inv;                         // D'  * 10^4
+    const double z = dn4 * (rq1s * rq2);
+    const double yr = z * dn4;                                           // r^2 * 10^4
+    const double kd = __builtin_rint(yd), kr = __builtin_rint(yr);
+    const double hd = __builtin_fma(inv, -k.cd, 0.499999);
+    const double hr = __builtin_fma(__builtin_fabs(z), -k.cr, 0.499999);
+    const bool sure = __builtin_fabs(yd - kd) < hd && __builtin_fabs(yr - kr) < hr &&
+                      __builtin_fmax(yd, yr) < 1e7 && dn4 != 0.0;
+    const bool degenerate = inv == __builtin_inf();
+    slow = !(sure || degenerate);
+    ldx_ld32 o;
+    const float vd = (float)(kd * 1e-4), vr = (float)(kr * 1e-4);        // float32 nearest to k / 10^4
+    o.d_prime = degenerate ? -0.0f : vd;
+    o.r_square = degenerate ? -0.0f : vr;
+    return o;
+}
+
 }  // namespace ldx

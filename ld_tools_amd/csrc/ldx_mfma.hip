@@ -25,6 +25,8 @@
 //     the popcount kernel and the oracle.
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "ldx_common.h"
 #include "ldx_tile.h"
 
@@ -32,24 +34,57 @@ namespace ldx {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
 
-#ifndef LDX_MFMA_WAVES
-#define LDX_MFMA_WAVES 4   // waves per workgroup: 4 (two workgroups per CU) or 8 (one per CU, B shared 8 ways)
-#endif
-constexpr int kMfmaWaves = LDX_MFMA_WAVES;
+// global loads the compiler does not track (see the K loop): the caller waits with s_waitcnt vmcnt(N)
+__device__ __forceinline__ void gload16(v4u &dst, const v4u *p)
+{
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p));
+}
+__device__ __forceinline__ void gload16_512(v4u &dst, const v4u *p)   // p + 512 bytes (the rows 32 further down)
+{
+    asm volatile("global_load_dwordx4 %0, %1, off offset:512" : "=v"(dst) : "v"(p));
+}
+__device__ __forceinline__ void gload8(v2u &dst, const uint2 *p)
+{
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(p));
+}
+
+constexpr int kMfmaWaves = 4;   // waves per workgroup; two workgroups per CU
 constexpr int kMfmaThreads = kMfmaWaves * 64;
 constexpr uint32_t kRows64 = 64;              // i-rows per wave unit
 constexpr uint32_t kBRow = 144;               // bytes per expanded j-row in LDS (128 + 16 pad)
 constexpr uint32_t kBBuf = kSlab * kBRow;     // one buffer: 18 KiB
+[[maybe_unused]] constexpr uint32_t kStampPasses = 40, kStampStride = 6 + 4 * kStampPasses;   // tuning builds: LDX_STAMP
 
-// 16 haplotype bits (bits 0..15 of `bits`) -> 16 bytes of 0/1
+// Bits to int8 operands.  The matrix pipe only needs A[k] * B[k] to be the SAME constant for every haplotype k
+// that both rows carry, not 1: the A side turns hap bit i of a nibble into the byte 1 << i (a byte replicate
+// + one AND per four haplotypes), the B side into 8 >> i (multiply-spread), so every co-occurrence adds 8 and
+// the accumulators hold 8 * n11 (< 2^31 for every panel whose counts fit 28 bits).
+
+// B side: 16 haplotype bits (bits 0..15 of `bits`) -> 16 bytes {8,4,2,1}[k % 4] or 0.
+// nibble bit i -> bit 7i + 3: byte i, bit 3 - i (multiplier bits at 6i + 3; no two products coincide)
 __device__ __forceinline__ v4i expand16(uint32_t bits)
 {
     v4i r;
-    r.x = (int)(((bits & 0xFu) * 0x00204081u) & 0x01010101u);
-    r.y = (int)((((bits >> 4) & 0xFu) * 0x00204081u) & 0x01010101u);
-    r.z = (int)((((bits >> 8) & 0xFu) * 0x00204081u) & 0x01010101u);
-    r.w = (int)((((bits >> 12) & 0xFu) * 0x00204081u) & 0x01010101u);
+    r.x = (int)(((bits & 0xFu) * 0x00208208u) & 0x01020408u);
+    r.y = (int)((((bits >> 4) & 0xFu) * 0x00208208u) & 0x01020408u);
+    r.z = (int)((((bits >> 8) & 0xFu) * 0x00208208u) & 0x01020408u);
+    r.w = (int)((((bits >> 12) & 0xFu) * 0x00208208u) & 0x01020408u);
+    return r;
+}
+
+// A side: 16 haplotype bits of `word` (its low or high half, chosen by the byte selectors) -> 16 bytes
+// {1,2,4,8}[k % 4] or 0: v_perm_b32 replicates a byte four times, the mask keeps bit i in byte i.
+__device__ __forceinline__ v4i expand16_a(uint32_t word, uint32_t sel0, uint32_t sel1)
+{
+    const uint32_t p0 = __builtin_amdgcn_perm(word, word, sel0), p1 = __builtin_amdgcn_perm(word, word, sel1);
+    v4i r;
+    r.x = (int)(p0 & 0x08040201u);
+    r.y = (int)((p0 >> 4) & 0x08040201u);
+    r.z = (int)(p1 & 0x08040201u);
+    r.w = (int)((p1 >> 4) & 0x08040201u);
     return r;
 }
 
@@ -57,12 +92,18 @@ __device__ __forceinline__ v4i expand16(uint32_t bits)
 #ifdef LDX_AB_NOAEXP
 #define EXPAND_A(x) v4i{(int)(x), 1, 1, 1}
 #else
-#define EXPAND_A(x) expand16(x)
+#define EXPAND_A(x) expand16_a(x, sel0, sel1)
 #endif
 #ifdef LDX_AB_NOBEXP
 #define EXPAND_B(x) v4i{(int)(x), 1, 1, 1}
 #else
 #define EXPAND_B(x) expand16(x)
+#endif
+
+#ifdef LDX_AB_NOSTREAM   // every chunk re-reads chunk 0: the K loop without memory latency
+#define LDX_AB_CHUNK(c) ((c) & 0u)
+#else
+#define LDX_AB_CHUNK(c) (c)
 #endif
 
 __device__ __forceinline__ uint32_t word_of(const uint4 &v, int w)
@@ -80,78 +121,133 @@ __device__ __forceinline__ void expand_b_share(uint2 bits, unsigned char *buf, u
     dst[3] = expand16(bits.y >> 16);
 }
 
+// passes of the full triangle before j-tile t: tile s has 2 * (n_slabs - s) units = ceil((n_slabs - s) / 2) passes
+__host__ __device__ inline uint32_t mfma_pass_base(uint32_t t, uint32_t n_slabs)
+{
+    auto c = [](uint32_t k) { return ((k + 1u) / 2u) * ((k + 2u) / 2u); };   // sum of ceil(m / 2), m = 1..k
+    return c(n_slabs) - c(n_slabs - t);
+}
+
+// ticket counters of the dynamic pass scheduler: {next ticket, workgroups finished}; self-resetting, one pair
+// per launch in flight (round-robin over a pool, so launches on different streams do not share a pair)
+constexpr uint32_t kSchedSlots = 256;
+__device__ uint32_t g_sched[kSchedSlots][2];
+
 template <bool kRaw, bool kN11>
 __global__ void __launch_bounds__(kMfmaThreads, 2)
 triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ fa, const double *__restrict__ fr,
                      const double *__restrict__ q, uint32_t n_snps, uint32_t n_slabs, uint32_t nchunks, double n,
                      double rn, uint64_t u_begin, uint64_t u_end, ldx_ld32 *__restrict__ out, ldx_ld64 *__restrict__ raw,
-                     uint32_t *__restrict__ n11, int ablate_arg)
+                     uint32_t *__restrict__ n11, uint32_t p_begin, uint32_t p_end, uint32_t *sched, int ablate_arg,
+                     unsigned long long *stamps)
 {
-    // experiment 64: workgroups of the first half of the grid run the K loop only, the others the epilogue
-    // only (do the two phases overlap when they sit on the same SIMD?); 128: only the first half works
+    // `ablate` (tuning builds only, -DLDX_TUNING + env LDX_ABLATE; a compile-time 0 in the product, so that
+    // none of its tests survives as a branch): 1 = no epilogue arithmetic, 2 = one chunk instead of all (no
+    // counting), 4 = no stores, 8 = no stagger, 64 = first half of the grid K loop only / second half epilogue
+    // only, 128 = only the first half of the grid works.  Results are wrong by design when it is non-zero.
+#ifdef LDX_TUNING
     int ablate = ablate_arg;
     if (ablate_arg & 64) ablate = (blockIdx.x < (gridDim.x + 1) / 2) ? (5 | 8) : (2 | 8);
     if ((ablate_arg & 128) && blockIdx.x >= (gridDim.x + 1) / 2) return;
-    // `ablate` (env LDX_ABLATE, tuning only; 0 in production): 1 = no epilogue arithmetic, 2 = one chunk
-    // instead of all (no counting), 4 = no stores.  Results are wrong by design when it is non-zero.
+#else
+    constexpr int ablate = 0;
+    (void)ablate_arg;
+    (void)stamps;
+#endif
     extern __shared__ uint4 lds[];
     unsigned char *bexp = reinterpret_cast<unsigned char *>(lds);   // [2][128][144]
+    // per-SNP operands of the fast epilogue (ldx_common.h, FastCol / FastRow): the j-tile's 128 columns, written
+    // once per tile, and this wave's 64 rows, written once per pass
+    double *cstat = reinterpret_cast<double *>(bexp + 2u * kBBuf);   // [128][4]
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t l32 = lane & 31u;
     const uint32_t half = lane >> 5;
-    const uint32_t sh = half * 16u;
+    const uint32_t sel0 = half ? 0x02020202u : 0x00000000u;   // v_perm selectors: this lane's two bytes of an A word
+    const uint32_t sel1 = half ? 0x03030303u : 0x01010101u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double *rstat = cstat + kSlab * 4u + wave * (kRows64 * 4u);       // [64][4], private to the wave
+    const FastConst fk = fast_const(n, 8.0);
+    // In-kernel stamps (tuning builds, env LDX_STAMPS=file): per wave {HW_ID | XCC_ID << 32, realtime, passes}
+    // and per pass {start, prologue done, K loop done, epilogue done} in shader cycles; written to a buffer nothing else reads.
+#ifdef LDX_TUNING
+    uint32_t npass = 0;
+    unsigned long long *const my_stamps = stamps ? stamps + (size_t)(blockIdx.x * kMfmaWaves + wave) * kStampStride : nullptr;
+    if (my_stamps && lane == 0) {
+        my_stamps[0] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) |
+                       ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
+        my_stamps[1] = __builtin_amdgcn_s_memrealtime();
+        my_stamps[2] = __builtin_amdgcn_s_memtime();
+    }
+#define LDX_STAMP(slot)                                                                                    \
+    do {                                                                                                   \
+        if (my_stamps && lane == 0 && npass < kStampPasses) my_stamps[6 + npass * 4 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define LDX_STAMP(slot)
+#endif
 
     // 64-row units: tile t owns groups g64 in [2t, 2T); unit v <-> small units [8v, 8v+8)
     const uint64_t G64 = (uint64_t)n_slabs * 2u;
     auto base64 = [&](uint64_t t) { return t * G64 - t * (t - 1u); };
     const uint64_t v_begin = u_begin / 8u, v_end = (u_end + 7u) / 8u;   // units that intersect the range
-    const uint64_t total = v_end - v_begin;
-    const uint64_t b0 = v_begin + total * blockIdx.x / gridDim.x;
-    const uint64_t b1 = v_begin + total * (blockIdx.x + 1) / gridDim.x;
-    if (b0 >= b1) return;   // block-uniform
 
-    // Stagger: all workgroups do identical work, so the two that share a CU would run their K loops
-    // (matrix pipe) and their epilogues (VALU) at the same time and the pipes would take turns.  The
-    // second half of the grid (dispatched onto the CUs' second slots) starts half a period late, so one
-    // workgroup's epilogue runs beside the other's K loop.  Speed only; any placement is correct.
-    const bool late = (ablate & 16) ? (blockIdx.x & 1u) != 0 : ((ablate & 32) ? ((blockIdx.x >> 3) & 1u) != 0
-                                                                              : blockIdx.x >= (gridDim.x + 1) / 2);
-    if ((ablate & 8) == 0 && late && b1 - b0 >= 8) {
+    // Work items are PASSES: four consecutive units of one j-tile, one per wave.  Pass p of the whole triangle
+    // (mfma_pass_base below: tile t's passes start at pass_base(t)) is handed out dynamically -- a ticket
+    // counter in global memory, one atomic per workgroup and pass, drawn one pass ahead -- because workgroups
+    // do not run at the same speed: two that share a CU and fall into step (K loop beside K loop, epilogue
+    // beside epilogue) take ~1.5x as long per pass as two in antiphase, and with an equal static share the
+    // slowest pair set the kernel time (max wave lifetime 826k cycles against a median of 533k at 10k SNPs).
+    uint32_t *tickets = reinterpret_cast<uint32_t *>(cstat + kSlab * 4u + kMfmaWaves * (kRows64 * 4u));   // [2]
+    auto draw = [&]() { return atomicAdd(&sched[0], 1u); };
+    uint32_t parity = 0;
+    if (tid == 0) tickets[0] = draw();
+
+    // Stagger: the second half of the grid (dispatched onto the CUs' second slots) starts half a period late,
+    // so that one workgroup's epilogue (VALU) runs beside the other's K loop (matrix pipe).  Speed only.
+    const bool late = blockIdx.x >= (gridDim.x + 1) / 2;
+    if ((ablate & 8) == 0 && late && p_end - p_begin >= 2u * gridDim.x) {
         const uint32_t naps = nchunks / 4 + 8;   // ~ (nchunks * 1024 + 32k) / 2 cycles in naps of 64 * 32
         for (uint32_t k = 0; k < naps; ++k) __builtin_amdgcn_s_sleep(32);
     }
 
-    uint32_t t;
-    {
-        uint32_t lo = 0, hi = n_slabs;   // largest t with base64(t) <= b0
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) / 2;
-            if (base64(mid) <= b0) lo = mid; else hi = mid;
+    uint32_t t_prev = 0xFFFFFFFFu;
+    for (;;) {   // block-uniform: every wave reaches every barrier
+        __syncthreads();   // the ticket is in LDS; every wave is past its previous epilogue (both B buffers free)
+        const uint32_t ticket = tickets[parity];
+        parity ^= 1u;
+        if (ticket >= p_end - p_begin) {   // block-uniform; the last workgroup out re-arms the counters
+            if (tid == 0 && atomicAdd(&sched[1], 1u) == gridDim.x - 1u) {
+                sched[1] = 0u;
+                __threadfence();
+                sched[0] = 0u;
+            }
+            break;
         }
-        t = lo;
-    }
-    uint64_t v = b0;
-    while (v < b1) {   // block-uniform: every wave reaches every barrier
+        const uint32_t p = p_begin + ticket;
+        uint32_t t;
+        {
+            uint32_t lo = 0, hi = n_slabs;   // largest t with pass_base(t) <= p
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) / 2;
+                if (mfma_pass_base(mid, n_slabs) <= p) lo = mid; else hi = mid;
+            }
+            t = lo;
+        }
+        const bool new_tile = t != t_prev;
+        t_prev = t;
         const uint64_t tb = base64(t), te = base64(t + 1u);
-        const uint64_t seg_end = b1 < te ? b1 : te;
+        const uint64_t pass = tb + (uint64_t)(p - mfma_pass_base(t, n_slabs)) * kMfmaWaves;   // its first unit
+        const uint64_t seg_begin = v_begin > tb ? v_begin : tb, seg_end = v_end < te ? v_end : te;
         // the j-tile's bits for this thread's expansion share: row tid/2, 8 bytes (tid%2) of each chunk
-#if LDX_MFMA_WAVES == 8
-        // 512 threads: row tid/4, one 32-bit word (tid%4) of each chunk
-        const uint32_t *bsrc = reinterpret_cast<const uint32_t *>(alt + (size_t)t * nchunks * kSlab) + tid;
-        constexpr uint32_t kBStride = kSlab * 4u;   // words per chunk
-        const uint32_t b_off = (tid >> 2) * kBRow + (tid & 3u) * 32u;
-#else
         const uint2 *bsrc = reinterpret_cast<const uint2 *>(alt + (size_t)t * nchunks * kSlab) + tid;
         constexpr uint32_t kBStride = kSlab * 2u;   // uint2 per chunk
         const uint32_t b_off = (tid >> 1) * kBRow + (tid & 1u) * 64u;
-#endif
 
-        for (uint64_t pass = v; pass < seg_end; pass += kMfmaWaves) {   // block-uniform
+        {
             const uint64_t vv = pass + wave;
-            const bool active = vv < seg_end;
-            const uint32_t g64 = (uint32_t)((active ? vv : pass) - tb) + 2u * t;
+            const bool active = vv >= seg_begin && vv < seg_end;
+            const uint32_t g64 = (uint32_t)((vv < te ? vv : pass) - tb) + 2u * t;   // a row group inside the panel either way
             const uint32_t row0 = g64 * kRows64;
             // this lane's A rows: row0 + 32*m + l32 (both inside one slab: 64 | 128)
             const uint4 *ai = alt + ((size_t)(row0 / kSlab) * nchunks) * kSlab + (row0 % kSlab) + l32;
@@ -186,7 +282,11 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
                     for (int tt = 0; tt < 4; ++tt)
+#ifdef LDX_AB_NOMFMA
+                        asm volatile("" : "+v"(acc[m][tt]) : "v"(af[m]), "v"(bf[tt]));   // operands stay live, no work
+#else
                         acc[m][tt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[m], bf[tt], acc[m][tt], 0, 0, 0);
+#endif
             };
             auto interleave = [&]() {   // 8 x {1 MFMA, 5 VALU}: the VALU work of a step hides behind its MFMAs
                 // the next step's four B-fragment reads go FIRST: a whole step (256 cycles) of cover for the LDS
@@ -208,41 +308,57 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 __builtin_amdgcn_sched_barrier(0);
             };
 
-            __syncthreads();   // the previous pass has finished reading both buffers
-            {   // chunk 0 -> buffer 0
-                v4i *d0 = reinterpret_cast<v4i *>(bexp + b_off);
-#if LDX_MFMA_WAVES == 8
-                const uint32_t w0 = bsrc[0];
-                d0[0] = expand16(w0);
-                d0[1] = expand16(w0 >> 16);
-#else
-                const uint2 w0 = bsrc[0];
+            LDX_STAMP(0);
+            // Global loads of the K loop are issued by hand (global_load in inline asm) and waited for by hand
+            // (s_waitcnt vmcnt(N) with N = the loads allowed to stay in flight): hipcc's own counter tracking gives
+            // up at the loop's control-flow joins and emitted vmcnt(0) right after issuing a batch, i.e. one full
+            // memory latency per chunk (K loop 1960 cycles per chunk instead of ~1150).  Rules that keep this
+            // sound: every asm load is followed, before the first C++ use of its register, by a wait that covers
+            // it and by ring_touch(), which ties the register to that point of the program order; the ring is
+            // statically indexed (chunk loop unrolled by 3), so no register with a load in flight is ever copied.
+            v4u ar[3][2];   // A words: ring slot k holds the chunk c with c % 3 == k
+            v2u br[3];      // this thread's 8 bytes of the j-tile's chunk (B expansion share)
+            auto clampc = [&](uint32_t c) { return c < nchunks ? c : nchunks - 1u; };   // surplus loads are discarded
+            {
+                v2u w0;
+                gload8(w0, bsrc);
+                gload8(br[1], bsrc + (size_t)clampc(1) * kBStride);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const v4u *src = reinterpret_cast<const v4u *>(ai + (size_t)clampc(k) * kSlab);
+                    gload16(ar[k][0], src);
+                    gload16_512(ar[k][1], src);
+                }
+                asm volatile("s_waitcnt vmcnt(0)");
+                asm volatile("" : "+v"(w0), "+v"(br[1]), "+v"(ar[0][0]), "+v"(ar[0][1]), "+v"(ar[1][0]), "+v"(ar[1][1]));
+                v4i *d0 = reinterpret_cast<v4i *>(bexp + b_off);   // chunk 0 -> buffer 0
                 d0[0] = expand16(w0.x);
                 d0[1] = expand16(w0.x >> 16);
                 d0[2] = expand16(w0.y);
                 d0[3] = expand16(w0.y >> 16);
-#endif
             }
-            // Global prefetch ring, 3 chunks deep, statically indexed (the chunk loop is unrolled by 3 so no
-            // register is ever MOVED: a move of a register with a load in flight is a wait).  During chunk c
-            // the loads of chunk c+2 are issued; the A words are first touched at the end of chunk c+1 (the j
-            // bits, re-read by every pass of the tile and therefore cache-hot, at its start).  With one chunk of
-            // cover the K loop ran at the latency of those loads (~1900 cycles per chunk, matrix pipe 47 % busy
-            // for a lone wave) instead of at the 1024 cycles of its 32 MFMAs.
-            auto clampc = [&](uint32_t c) { return c < nchunks ? c : nchunks - 1u; };   // surplus loads are discarded
-            uint4 ar[3][2];
-            decltype(bsrc[0] + 0) br[3];
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                br[k] = bsrc[(size_t)clampc(k) * kBStride];
-#pragma unroll
-                for (int m = 0; m < 2; ++m) ar[k][m] = ai[(size_t)clampc(k) * kSlab + 32 * m];
+            if (!kRaw) {   // epilogue operands -> LDS (every wave is past its previous epilogue: barrier above)
+                if (new_tile && tid < kSlab) {
+                    const uint32_t j = t * kSlab + tid;
+                    const FastCol c = fast_col(fa[j], fr[j], n);
+                    typedef double d2 __attribute__((ext_vector_type(2)));
+                    d2 *dst = reinterpret_cast<d2 *>(cstat + tid * 4u);
+                    dst[0] = d2{c.a, c.ra};
+                    dst[1] = d2{c.rr, c.rq};
+                }
+                const uint32_t i = row0 + lane;
+                const FastRow r = fast_row(fa[i], fr[i], n);
+                typedef double d2 __attribute__((ext_vector_type(2)));
+                d2 *dst = reinterpret_cast<d2 *>(rstat + lane * 4u);
+                dst[0] = d2{r.a_s, r.ra};
+                dst[1] = d2{r.rr, r.rq_s};
             }
             __syncthreads();
+            LDX_STAMP(1);
             v4i af0[2], bf0[4], af1[2], bf1[4];
             read_bf(bf0, bexp, 0);
 #pragma unroll
-            for (int m = 0; m < 2; ++m) af0[m] = EXPAND_A(ar[0][m].x >> sh);
+            for (int m = 0; m < 2; ++m) af0[m] = EXPAND_A(ar[0][m].x);
 
             const uint32_t nch_run = (ablate & 2) ? 1u : nchunks;
             // one chunk: ring slot CUR holds its A words, slot NXT the next chunk's (A words and B bits),
@@ -253,69 +369,95 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 const unsigned char *rd = bexp + (c_ & 1u) * kBBuf;                                                \
                 unsigned char *wr = bexp + ((c_ + 1u) & 1u) * kBBuf;                                               \
                 v4i *bdst = reinterpret_cast<v4i *>(wr + b_off);                                                   \
-                const uint32_t c3 = clampc(c_ + 2u);                                                               \
-                /* B bits FIRST: vmcnt counts in order, so waiting for them (next chunk, step 0) must not */      \
-                /* also wait for this batch's A words (needed only at the end of the next chunk) */               \
-                br[FAR] = bsrc[(size_t)c3 * kBStride];                                                             \
-                __builtin_amdgcn_sched_barrier(0);                                                                 \
-                _Pragma("unroll") for (int m = 0; m < 2; ++m) ar[FAR][m] = ai[(size_t)c3 * kSlab + 32 * m];        \
+                const uint32_t c3 = LDX_AB_CHUNK(clampc(c_ + 2u));                                                 \
+                /* loads of chunk c+2, B bits FIRST (vmcnt counts in issue order).  In flight now, oldest first: */ \
+                /* chunk c+1's {B, A, A} and this batch's {B, A, A}; step 0 needs the former B: 5 may stay */       \
+                gload8(br[FAR], bsrc + (size_t)c3 * kBStride);                                                     \
+                {                                                                                                  \
+                    const v4u *src_ = reinterpret_cast<const v4u *>(ai + (size_t)c3 * kSlab);                      \
+                    gload16(ar[FAR][0], src_);                                                                     \
+                    gload16_512(ar[FAR][1], src_);                                                                 \
+                }                                                                                                  \
+                asm volatile("s_waitcnt vmcnt(5)");                                                                \
+                asm volatile("" : "+v"(br[NXT]));                                                                  \
                 /* step 0: MFMAs of (c,0); prepare (c,1); first half of this thread's share of B chunk c+1 */     \
                 read_bf(bf1, rd, 1);                                                                               \
-                _Pragma("unroll") for (int m = 0; m < 2; ++m) af1[m] = EXPAND_A(ar[CUR][m].y >> sh);               \
+                _Pragma("unroll") for (int m = 0; m < 2; ++m) af1[m] = EXPAND_A(ar[CUR][m].y);               \
                 LDX_BSHARE_0(br[NXT]);                                                                             \
                 mma8(af0, bf0);                                                                                    \
                 interleave();                                                                                      \
                 __builtin_amdgcn_sched_barrier(0);                                                                 \
                 /* step 1: MFMAs of (c,1); prepare (c,2); second half of the B share */                           \
                 read_bf(bf0, rd, 2);                                                                               \
-                _Pragma("unroll") for (int m = 0; m < 2; ++m) af0[m] = EXPAND_A(ar[CUR][m].z >> sh);               \
+                _Pragma("unroll") for (int m = 0; m < 2; ++m) af0[m] = EXPAND_A(ar[CUR][m].z);               \
                 LDX_BSHARE_1(br[NXT]);                                                                             \
                 mma8(af1, bf1);                                                                                    \
                 interleave();                                                                                      \
                 __builtin_amdgcn_sched_barrier(0);                                                                 \
                 /* step 2: MFMAs of (c,2); prepare (c,3) */                                                       \
                 read_bf(bf1, rd, 3);                                                                               \
-                _Pragma("unroll") for (int m = 0; m < 2; ++m) af1[m] = EXPAND_A(ar[CUR][m].w >> sh);               \
+                _Pragma("unroll") for (int m = 0; m < 2; ++m) af1[m] = EXPAND_A(ar[CUR][m].w);               \
                 mma8(af0, bf0);                                                                                    \
                 interleave();                                                                                      \
                 lds_barrier(); /* chunk c+1 complete in `wr`; nobody reads `rd` any more */                       \
-                /* step 3: MFMAs of (c,3); prepare (c+1,0) from the other buffer and the next A chunk */          \
+                /* step 3: MFMAs of (c,3); prepare (c+1,0) from the other buffer and the next A chunk, whose */   \
+                /* words must have landed: only this chunk's batch of 3 may still be in flight */                 \
+                asm volatile("s_waitcnt vmcnt(3)");                                                                \
+                asm volatile("" : "+v"(ar[NXT][0]), "+v"(ar[NXT][1]));                                             \
                 read_bf(bf0, wr, 0);                                                                               \
-                _Pragma("unroll") for (int m = 0; m < 2; ++m) af0[m] = EXPAND_A(ar[NXT][m].x >> sh);               \
+                _Pragma("unroll") for (int m = 0; m < 2; ++m) af0[m] = EXPAND_A(ar[NXT][m].x);               \
                 mma8(af1, bf1);                                                                                    \
                 interleave();                                                                                      \
                 __builtin_amdgcn_sched_barrier(0);                                                                 \
             }
-#if LDX_MFMA_WAVES == 8
-#define LDX_BSHARE_0(bits) bdst[0] = EXPAND_B(bits)
-#define LDX_BSHARE_1(bits) bdst[1] = EXPAND_B((bits) >> 16)
-#else
 #define LDX_BSHARE_0(bits) bdst[0] = EXPAND_B((bits).x); bdst[1] = EXPAND_B((bits).x >> 16)
 #define LDX_BSHARE_1(bits) bdst[2] = EXPAND_B((bits).y); bdst[3] = EXPAND_B((bits).y >> 16)
-#endif
             for (uint32_t c = 0; c < nch_run; c += 3) {   // block-uniform guards: every wave reaches every barrier
                 LDX_CHUNK(0, 1, 2, c)
                 if (c + 1 < nch_run) LDX_CHUNK(1, 2, 0, c + 1)
                 if (c + 2 < nch_run) LDX_CHUNK(2, 0, 1, c + 2)
             }
 #undef LDX_CHUNK
+            // drain the surplus loads of the last two chunks: their ring registers are about to be reused
+            asm volatile("s_waitcnt vmcnt(0)");
+            asm volatile("" : "+v"(ar[0][0]), "+v"(ar[0][1]), "+v"(ar[1][0]), "+v"(ar[1][1]), "+v"(ar[2][0]), "+v"(ar[2][1]),
+                         "+v"(br[0]), "+v"(br[1]), "+v"(br[2]));
 #undef LDX_BSHARE_0
 #undef LDX_BSHARE_1
 
-            if (!active) continue;   // wave-uniform; inactive waves only helped with B and the barriers
-            // epilogue: acc[m][tt][e] is pair (i, j) with
+            LDX_STAMP(2);
+            // the next pass's ticket: drawn here (after the K loop's hand-counted loads), stored to LDS after the
+            // epilogue, so the atomic's latency hides behind it
+            uint32_t next_ticket = 0;
+            if (tid == 0) next_ticket = draw();
+            if (!active) {   // wave-uniform; inactive waves only helped with B and the barriers
+                if (tid == 0) tickets[parity] = next_ticket;
+                continue;
+            }
+            // epilogue: acc[m][tt][e] is 8 * n11 of pair (i, j) with
             //   i = row0 + 32*m + (e & 3) + 8*(e >> 2) + 4*half,  j = 128*t + 32*tt + l32
-            double fa2[4], fr2[4];
+            typedef double d2 __attribute__((ext_vector_type(2)));
+            double fa2[4], fr2[4];     // kRaw: the mirror's column operands
+            FastCol fc[4];             // !kRaw: the fast epilogue's
+            double sfa = 0.0, sfr = 0.0, sq = 0.0;
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
-                fa2[tt] = fa[t * kSlab + 32u * tt + l32];
-                fr2[tt] = fr[t * kSlab + 32u * tt + l32];
+                if (kRaw) {
+                    fa2[tt] = fa[t * kSlab + 32u * tt + l32];
+                    fr2[tt] = fr[t * kSlab + 32u * tt + l32];
+                } else {
+                    const d2 *cs = reinterpret_cast<const d2 *>(cstat + (32u * tt + l32) * 4u);
+                    const d2 c01 = cs[0], c23 = cs[1];
+                    fc[tt] = FastCol{c01.x, c01.y, c23.x, c23.y};
+                }
             }
-            // one coalesced load per statistic for the unit's 64 rows (instead of a dependent global load per
-            // row inside the loop: 32 exposed latencies per unit)
-            const double sfa = fa[row0 + lane], sfr = fr[row0 + lane], sq = q[row0 + lane];
-            // The e-loop is NOT unrolled: 128 pairs x ~90 instructions would be ~90 KB of straight-line code
-            // per wave, more than the instruction cache two CUs share.  acc[..][..][e] with a wave-uniform e
+            if (kRaw) {   // one coalesced load per statistic for the unit's 64 rows, handed out by shuffles below
+                sfa = fa[row0 + lane];
+                sfr = fr[row0 + lane];
+                sq = q[row0 + lane];
+            }
+            // The e-loop is NOT unrolled: 128 pairs x ~50 instructions would be ~50 KB of straight-line code
+            // per wave, most of the instruction cache two CUs share.  acc[..][..][e] with a wave-uniform e
             // is a register-indirect move (s_set_gpr_idx_on), not scratch.
 #pragma unroll 1
             for (int e = 0; e < 16; ++e) {
@@ -323,45 +465,55 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 for (int m = 0; m < 2; ++m) {
                     const uint32_t ri = 32u * m + (e & 3) + 8u * (e >> 2) + 4u * half;   // row inside the unit
                     const uint32_t i = row0 + ri;
-                    // lane L preloaded the statistics of row row0 + L: fetch row ri's through the LDS crossbar
-                    const double fa1 = __shfl(sfa, (int)ri), fr1 = __shfl(sfr, (int)ri), q1 = __shfl(sq, (int)ri);
                     const uint64_t us = vv * 8u + ri / kGroup;   // the small unit this row belongs to
                     const bool in_range = us >= u_begin && us < u_end;
-                    // The four pairs of this row (one per column tile) go through the fast epilogue WITHOUT
-                    // branches -- invalid cells (row <= col, pad rows) are computed on whatever the registers
-                    // hold and zeroed by a select -- so their four dependent fp64 chains interleave; with a
-                    // branch per pair a lone wave spent 545 cycles per pair on a 50-instruction epilogue.
+                    // The four pairs of this row (one per column tile) go through the epilogue WITHOUT branches --
+                    // invalid cells (row <= col, pad rows) are computed on whatever the registers hold and zeroed
+                    // by a select -- so their four dependent fp64 chains interleave.
                     uint32_t cnt[4];
-                    double f11[4];
                     ldx_ld32 res[4];
                     ldx_ld64 rw[4];
                     bool valid[4], slow[4];
                     bool any_slow = false;
+                    if (kRaw) {   // parity / debugging output: the op-for-op mirror, unrounded values kept
+                        const double fa1 = __shfl(sfa, (int)ri), fr1 = __shfl(sfr, (int)ri), q1 = __shfl(sq, (int)ri);
 #pragma unroll
-                    for (int tt = 0; tt < 4; ++tt) {
-                        const uint32_t j = t * kSlab + 32u * tt + l32;
-                        valid[tt] = (i > j) && (i < n_snps);
-                        cnt[tt] = (uint32_t)acc[m][tt][e];
-                        f11[tt] = div_by_n((double)cnt[tt], n, rn);   // calc_ld.py:33
-                        rw[tt] = ldx_ld64{0.0, 0.0};
-                        if (ablate & 1) {   // tuning: no epilogue arithmetic
-                            res[tt] = ldx_ld32{(float)cnt[tt], 0.0f};
-                            slow[tt] = false;
-                        } else if (kRaw) {   // parity / debugging output: the op-for-op mirror, unrounded values kept
-                            const LdRaw lr = ld_epilogue(f11[tt], fa1, fr1, q1, fa2[tt], fr2[tt]);
+                        for (int tt = 0; tt < 4; ++tt) {
+                            const uint32_t j = t * kSlab + 32u * tt + l32;
+                            valid[tt] = (i > j) && (i < n_snps);
+                            cnt[tt] = (uint32_t)acc[m][tt][e] >> 3;
+                            const LdRaw lr = ld_epilogue((double)cnt[tt] / n, fa1, fr1, q1, fa2[tt], fr2[tt]);   // calc_ld.py:33
                             res[tt] = round_pair(lr);
-                            if (valid[tt]) rw[tt] = ldx_ld64{lr.rsq, lr.dprime};
+                            rw[tt] = valid[tt] ? ldx_ld64{lr.rsq, lr.dprime} : ldx_ld64{0.0, 0.0};
                             slow[tt] = false;
-                        } else {
-                            res[tt] = ld_pair_fast(f11[tt], fa1, fr1, q1, fa2[tt], fr2[tt], slow[tt]);
-                            slow[tt] = slow[tt] && valid[tt];
-                            any_slow = any_slow || slow[tt];
                         }
-                    }
-                    if (!kRaw && __builtin_expect(__any(any_slow), 0)) {   // near a rounding tie: the exact mirror
+                    } else {
+                        const d2 *rs = reinterpret_cast<const d2 *>(rstat + ri * 4u);   // two addresses per wave: broadcast
+                        const d2 r01 = rs[0], r23 = rs[1];
 #pragma unroll
-                        for (int tt = 0; tt < 4; ++tt)
-                            if (slow[tt]) res[tt] = ld_pair_mirror(f11[tt], fa1, fr1, q1, fa2[tt], fr2[tt]);
+                        for (int tt = 0; tt < 4; ++tt) {
+                            const uint32_t j = t * kSlab + 32u * tt + l32;
+                            valid[tt] = (i > j) && (i < n_snps);
+                            const int a8 = acc[m][tt][e];
+                            cnt[tt] = (uint32_t)a8 >> 3;
+                            if (ablate & 1) {   // tuning: no epilogue arithmetic
+                                res[tt] = ldx_ld32{(float)a8, 0.0f};
+                                slow[tt] = false;
+                            } else {
+                                res[tt] = ld_pair_fast2((double)a8, fk, r01.x, r01.y, r23.x, r23.y, fc[tt].a, fc[tt].ra,
+                                                        fc[tt].rr, fc[tt].rq, slow[tt]);
+                                slow[tt] = slow[tt] && valid[tt];
+                                any_slow = any_slow || slow[tt];
+                            }
+                        }
+                        if (__builtin_expect(__any(any_slow), 0)) {   // near a rounding tie, Dn == 0, ...: the exact mirror
+#pragma unroll
+                            for (int tt = 0; tt < 4; ++tt)
+                                if (slow[tt]) {
+                                    const uint32_t j = t * kSlab + 32u * tt + l32;
+                                    res[tt] = ld_pair_mirror((double)cnt[tt] / n, fa[i], fr[i], q[i], fa[j], fr[j]);
+                                }
+                        }
                     }
                     if (in_range && !(ablate & 4)) {
 #pragma unroll
@@ -370,7 +522,6 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                             const size_t o = (size_t)(us - u_begin) * LDX_UNIT_PAIRS + (size_t)(ri % kGroup) * kSlab + jl;
                             ldx_ld32 w = res[tt];
                             if (!valid[tt]) w = ldx_ld32{0.0f, 0.0f};
-                            if (ablate & 1) w.r_square = (float)cnt[tt];
                             out[o] = w;
                             if (kRaw) raw[o] = rw[tt];
                             if (kN11) n11[o] = valid[tt] ? cnt[tt] : 0u;
@@ -378,9 +529,17 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                     }
                 }
             }
+            if (tid == 0) tickets[parity] = next_ticket;
+#ifdef LDX_TUNING
+            LDX_STAMP(3);
+            ++npass;
+            if (my_stamps && lane == 0) {
+                my_stamps[3] = npass;
+                my_stamps[4] = __builtin_amdgcn_s_memrealtime();
+                my_stamps[5] = __builtin_amdgcn_s_memtime();
+            }
+#endif
         }
-        v = seg_end;
-        ++t;
     }
 }
 
@@ -390,22 +549,69 @@ static int launch_mfma(const void *alt, const double *fa, const double *fr, cons
                        uint32_t *out_n11, hipStream_t s)
 {
     const uint32_t nch = n_chunks(n_hap);
-    const size_t lds = 2u * kBBuf;
+    const size_t lds = 2u * kBBuf + (kSlab + kMfmaWaves * kRows64) * 4u * sizeof(double) + 16u;
     int dev = 0, cus = 256;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
         prop.multiProcessorCount > 0)
         cus = prop.multiProcessorCount;
-    const uint64_t total = (unit_end + 7u) / 8u - unit_begin / 8u;
-    uint64_t grid = (uint64_t)cus * (8u / kMfmaWaves);   // persistent: 8 waves per CU (two 4-wave workgroups or one of 8)
-    const uint64_t max_grid = (total + kMfmaWaves - 1) / kMfmaWaves;
-    if (grid > max_grid) grid = max_grid;
+    // the range of passes that intersect [unit_begin, unit_end)
+    const uint32_t ns = n_slabs(n_snps);
+    const uint64_t G64 = (uint64_t)ns * 2u;
+    auto base64 = [&](uint64_t t) { return t * G64 - t * (t - 1u); };
+    auto tile_of = [&](uint64_t v) {
+        uint32_t lo = 0, hi = ns;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) / 2;
+            if (base64(mid) <= v) lo = mid; else hi = mid;
+        }
+        return lo;
+    };
+    const uint64_t v_begin = unit_begin / 8u, v_end = (unit_end + 7u) / 8u;
+    const uint32_t t0 = tile_of(v_begin), t1 = tile_of(v_end - 1u);
+    const uint32_t p_begin = mfma_pass_base(t0, ns) + (uint32_t)((v_begin - base64(t0)) / kMfmaWaves);
+    const uint32_t p_end = mfma_pass_base(t1, ns) + (uint32_t)((v_end - base64(t1) + kMfmaWaves - 1u) / kMfmaWaves);
+    uint64_t grid = (uint64_t)cus * (8u / kMfmaWaves);   // persistent: 8 waves per CU = two workgroups
+    if (grid > p_end - p_begin) grid = p_end - p_begin;
     if (grid < 1) grid = 1;
+    static uint32_t (*sched_pool)[2] = nullptr;
+    static std::atomic<uint32_t> sched_next{0};
+    if (!sched_pool) {
+        void *sym = nullptr;
+        LDX_HIP(hipGetSymbolAddress(&sym, HIP_SYMBOL(g_sched)));
+        sched_pool = reinterpret_cast<uint32_t (*)[2]>(sym);
+    }
+    uint32_t *sched = sched_pool[sched_next.fetch_add(1) % kSchedSlots];
+    int ablate = 0;
+    unsigned long long *stamps = nullptr;
+#ifdef LDX_TUNING
+    ablate = getenv("LDX_ABLATE") ? atoi(getenv("LDX_ABLATE")) : 0;
+    const char *stamp_file = getenv("LDX_STAMPS");
+    const size_t stamp_words = (size_t)grid * kMfmaWaves * kStampStride;
+    if (stamp_file) {
+        LDX_HIP(hipMalloc(&stamps, stamp_words * 8));
+        LDX_HIP(hipMemsetAsync(stamps, 0, stamp_words * 8, s));
+    }
+#endif
     triangle_mfma_kernel<kRaw, kN11><<<(uint32_t)grid, kMfmaThreads, lds, s>>>(
         (const uint4 *)alt, fa, fr, q, n_snps, n_slabs(n_snps), nch, (double)n_hap, 1.0 / (double)n_hap, unit_begin,
-        unit_end, out, out_raw,
-        out_n11, getenv("LDX_ABLATE") ? atoi(getenv("LDX_ABLATE")) : 0);
+        unit_end, out, out_raw, out_n11, p_begin, p_end, sched, ablate, stamps);
     LDX_HIP(hipGetLastError());
+#ifdef LDX_TUNING
+    if (stamps) {   // tuning only: synchronous; the file holds the stamps of the LAST launch
+        unsigned long long *h = (unsigned long long *)malloc(stamp_words * 8);
+        LDX_HIP(hipStreamSynchronize(s));
+        LDX_HIP(hipMemcpy(h, stamps, stamp_words * 8, hipMemcpyDeviceToHost));
+        if (FILE *f = fopen(stamp_file, "wb")) {
+            const unsigned long long hdr[4] = {grid, (unsigned long long)kMfmaWaves, kStampStride, kStampPasses};
+            fwrite(hdr, 8, 4, f);
+            fwrite(h, 8, stamp_words, f);
+            fclose(f);
+        }
+        free(h);
+        LDX_HIP(hipFree(stamps));
+    }
+#endif
     return LDX_OK;
 }
 

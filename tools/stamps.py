@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Summarise the in-kernel stamps of a tuning build (LDX_STAMPS=file): placement, clock, cycles per phase."""
+import sys
+import numpy as np
+
+raw = np.fromfile(sys.argv[1], dtype=np.uint64)
+grid, waves, stride, passes = (int(x) for x in raw[:4])
+st = raw[4:].reshape(grid * waves, stride)
+st = st[st[:, 3] > 0]
+hw = st[:, 0]
+wave_id = hw & 0xF; simd = (hw >> 4) & 3; cu = (hw >> 8) & 0xF; sh = (hw >> 12) & 1; se = (hw >> 13) & 7; xcc = (hw >> 32) & 0xF
+cu_key = (xcc << 8) | (se << 5) | (sh << 4) | cu
+simd_key = (cu_key << 2) | simd
+print(f"waves with work: {len(st)}  distinct CUs: {len(np.unique(cu_key))}  distinct SIMDs: {len(np.unique(simd_key))}")
+_, cnt = np.unique(simd_key, return_counts=True)
+print("waves per SIMD histogram:", dict(zip(*np.unique(cnt, return_counts=True))))
+clk = (st[:, 5] - st[:, 2]).astype(np.float64) / ((st[:, 4] - st[:, 1]).astype(np.float64) / 100e6) / 1e9
+print(f"in-kernel clock GHz: median {np.median(clk):.3f}  min {clk.min():.3f}  max {clk.max():.3f}")
+life = (st[:, 5] - st[:, 2]).astype(np.float64)
+print(f"wave lifetime cycles: median {np.median(life):.0f}  max {life.max():.0f}")
+np_ = np.minimum(st[:, 3].astype(int), passes)
+k, e, g, pr = [], [], [], []
+for row, n in zip(st, np_):
+    s = row[6:6 + 4 * n].reshape(n, 4).astype(np.int64)
+    pr.append(s[:, 1] - s[:, 0]); k.append(s[:, 2] - s[:, 1]); e.append(s[:, 3] - s[:, 2])
+    if n > 1:
+        g.append(s[1:, 0] - s[:-1, 3])
+k, e, pr = np.concatenate(k), np.concatenate(e), np.concatenate(pr)
+q = lambda a: "  ".join(f"p{p}={np.percentile(a, p):.0f}" for p in (5, 25, 50, 75, 95))
+print("prologue cycles per pass: ", q(pr), f" mean={pr.mean():.0f}")
+print("K loop cycles per pass:   ", q(k), f" mean={k.mean():.0f}")
+print("epilogue cycles per pass: ", q(e), f" mean={e.mean():.0f}")
+if g:
+    g = np.concatenate(g); print("gap between passes:       ", q(g))
+print(f"passes per wave: median {np.median(st[:,3]):.0f}")
