@@ -5,7 +5,7 @@
 
 One "step" = one full pass of the hot path over one synthetic panel that is already resident in HBM
 as packed slab shards: (N > 1: all-gather of the shards over RCCL) -> ld_triangle kernel over this
-rank's share of the pair list -> 8 bytes per pair (float32 r^2, float32 D', 4-decimal) written to HBM.
+rank's share of the pass list -> 8 bytes per pair (float32 r^2, float32 D', 4-decimal) written to HBM.
 
 Workload (BASELINE.json): N = 1 -> configs[1], ld_triangle 10 000 SNPs x 5008 haplotypes.  N > 1 keeps
 the pairs per GPU constant (weak scaling): S = 10 000 * sqrt(N) SNPs rounded up to whole 128-row slabs,
@@ -30,7 +30,8 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-VALU_PEAK_TOPS = 157.3 / 2                # ... 157.3 TFLOP/s fp32 vector = 78.65 T lane-instructions/s
+MFMA_I8_PEAK_TOPS = 5000.0                # ... dense I8 MFMA = 2x the BF16 rate per clock = ~5 POP/s (no sparsity)
+VALU_PEAK_TLANEOPS = 256 * 64 * 2.4e9 / 1e12   # AND / BCNT have no packed form: 64 lanes/clk/CU at 2.4 GHz = 39.3 T
 
 
 def parse():
@@ -43,7 +44,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--force-dist", action="store_true", help="run the sharded path (process group + all-gather) even at world 1")
-    ap.add_argument("--cpu-sample-snps", type=int, default=224)
+    ap.add_argument("--cpu-sample-snps", type=int, default=320)
+    ap.add_argument("--path", default="auto", choices=("auto", "mfma", "popcount"),
+                    help="kernel behind ld_triangle (auto = the int8 MFMA kernel; results are identical)")
     return ap.parse_args()
 
 
@@ -119,6 +122,8 @@ def main():
     from ld_tools_amd import PackedPanel, dist as ldist, ld_triangle, ops, synth
     from ld_tools_amd._lib import lib
 
+    ops.set_triangle_path(args.path)
+    mfma = args.path != "popcount"
     n_hap = args.haps
     if args.snps:
         n_snps = args.snps
@@ -175,20 +180,31 @@ def main():
         kern_ms = float(t.item())
 
     value = n_pairs * args.steps / dt
-    # ---- roofline of the dominant kernel (triangle_kernel), per launch, this rank's share ----
+    # ---- roofline of the dominant kernel, per launch, this rank's share ----
     my_pairs = n_pairs / world
+    kern_s = kern_ms * 1e-3
     alg_bytes = 8.0 * my_pairs + lib.ldx_plane_bytes(n_snps, n_hap)     # 8 B/pair out + the ALT plane read once
+    alg_ops = 2.0 * n_hap * my_pairs                                    # int8 multiply-adds x 2 (2*H per pair)
     lane_ops = 2.0 * math.ceil(n_hap / 32) * my_pairs                   # v_and_b32 + v_bcnt_u32_b32 per 32 haplotypes
-    achieved_gbs = alg_bytes / (kern_ms * 1e-3) / 1e9
     traffic = None
     tfile = ROOT / "profiles" / "traffic.json"
     if tfile.exists():
         try:
             rec = json.loads(tfile.read_text())
-            if rec.get("workload") == f"ld_triangle {n_snps}x{n_hap}" and rec.get("gpus") == world:
+            if (rec.get("workload") == f"ld_triangle {n_snps}x{n_hap}" and rec.get("gpus") == world
+                    and rec.get("path", "mfma") == ("mfma" if mfma else "popcount")):
                 traffic = rec.get("hbm_bytes_per_launch")
         except (ValueError, OSError):
             pass
+    hbm = {"bound": "hbm", "achieved": alg_bytes / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": alg_bytes / kern_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": alg_bytes}
+    if mfma:   # the counting runs on the matrix pipe: that ceiling governs (5 POP/s / 10 016 ops = 5.0e11 pairs/s)
+        roofline = {"bound": "mfma", "achieved": alg_ops / kern_s / 1e12, "peak": MFMA_I8_PEAK_TOPS, "unit": "TFLOP/s",
+                    "frac": alg_ops / kern_s / 1e12 / MFMA_I8_PEAK_TOPS, "traffic": traffic,
+                    "kernel": "triangle_mfma_kernel", "kernel_ms": kern_ms, "algorithmic_ops": alg_ops,
+                    "ops_per_pair": 2 * n_hap, "note": "int8 multiply-adds counted as 2 ops (integer, not floating point)"}
+    else:
+        roofline = dict(hbm, kernel="triangle_kernel", kernel_ms=kern_ms)
     line = {
         "metric": "SNP-pairs/sec (r2+D')",
         "value": value,
@@ -200,37 +216,23 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "u32 popcount + f64 epilogue",
+        "dtype": "int8" if mfma else "u32",
         "data": "synthetic",
         "config": {"workload": f"ld_triangle {n_snps}x{n_hap}", "n_snps": n_snps, "n_hap": n_hap,
                    "pairs_per_step": n_pairs, "output": "8 B/pair (f32 r2, f32 D', rounded to 4 decimals) in HBM",
-                   "sharding": "none" if world == 1 else f"row-block shards, all-gather, unit list / {world}"},
-        "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "triangle_kernel", "kernel_ms": kern_ms, "algorithmic_bytes": alg_bytes},
-        # the popcount path is VALU-bound, not HBM-bound (DESIGN.md "rooflines"): the governing ceiling
-        "roofline_valu": {"bound": "valu-int", "achieved": lane_ops / (kern_ms * 1e-3) / 1e12, "peak": VALU_PEAK_TOPS,
-                          "unit": "T lane-ops/s", "frac": lane_ops / (kern_ms * 1e-3) / 1e12 / VALU_PEAK_TOPS,
-                          "ops_per_pair": 2 * math.ceil(n_hap / 32)},
+                   "kernel_path": "int8 MFMA counts + f64 epilogue" if mfma else "AND+popcount counts + f64 epilogue",
+                   "sharding": "none" if world == 1 else f"row-block shards, all-gather, pass list / {world}"},
+        "roofline": roofline,
+        "roofline_hbm": hbm,      # the metric's "% HBM roofline": output bytes + one read of the packed plane
     }
-    if rank == 0 and world == 1:
-        # peak of the inner loop's instruction pair, measured with the same opcodes and no memory traffic
-        iters = 4000
-        cus = torch.cuda.get_device_properties(dev).multi_processor_count
-        ops.probe_andpop(cus, 1024, 10)
-        torch.cuda.synchronize()
-        a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        ops.probe_andpop(cus, 1024, iters)
-        b_.record()
-        torch.cuda.synchronize()
-        probe = cus * 1024 * iters * 128 / (a.elapsed_time(b_) * 1e-3) / 1e12
-        line["roofline_valu"]["probe_and_bcnt_Tops"] = probe
-        line["roofline_valu"]["frac_of_probe"] = line["roofline_valu"]["achieved"] / probe
-        if not args.no_cpu_baseline:
-            need = max(args.cpu_sample_snps, 1536)
-            host = codes_local[:need].cpu().numpy()
-            line["cpu_baseline"] = cpu_baseline(host, args.cpu_sample_snps)
+    if not mfma:   # the popcount path is bound by the integer VALU, not by HBM
+        line["roofline_valu"] = {"bound": "valu-int", "achieved": lane_ops / kern_s / 1e12, "peak": VALU_PEAK_TLANEOPS,
+                                 "unit": "T lane-ops/s", "frac": lane_ops / kern_s / 1e12 / VALU_PEAK_TLANEOPS,
+                                 "ops_per_pair": 2 * math.ceil(n_hap / 32)}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        need = max(args.cpu_sample_snps, 1536)
+        host = codes_local[:need].cpu().numpy()
+        line["cpu_baseline"] = cpu_baseline(host, args.cpu_sample_snps)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if use_dist:
