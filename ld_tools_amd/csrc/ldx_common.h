@@ -195,17 +195,25 @@ struct FastCol {   // per var_2 (column / opposing):  a,  1/a,  1/r,  1 / (a r)
     double a, ra, rr, rq;
 };
 struct FastConst {   // per launch
-    double nsc;      // 1e4 * n / count_scale   (count_scale = 8 on the MFMA path: its accumulators hold 8 * n11)
-    double cd, cr;   // margins per unit of 1/B and of |z| (see fast_const)
+    double nsc;        // 1e4 * n / count_scale   (count_scale = 8 on the MFMA path: its accumulators hold 8 * n11)
+    double ncd, ncr;   // minus the margins per unit of 1/B and of |z| (see fast_const)
 };
 
 __host__ __device__ inline FastConst fast_const(double n, double count_scale)
 {
     FastConst c;
     c.nsc = 1e4 * n / count_scale;   // exact: count_scale is 1 or 8 and n < 2^32
-    c.cd = 6e-12 * n * n;            // >= 1e4 * 4.5e-16 * n^2, with a third to spare
-    c.cr = 2.0 * c.cd;
+    c.ncd = -6e-12 * n * n;          // |.| >= 1e4 * 4.5e-16 * n^2, with a third to spare
+    c.ncr = 2.0 * c.ncd;
     return c;
+}
+
+// v_max_f64 as is: __builtin_fmax adds a canonicalising v_max x, x per operand (the operands here are never sNaN)
+__device__ __forceinline__ double max_raw(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 
 __device__ __forceinline__ FastRow fast_row(double fa, double fr, double n)
@@ -238,15 +246,16 @@ __device__ __forceinline__ ldx_ld32 ld_pair_fast2(double cnt_scaled, const FastC
     const double dn4 = __builtin_fma(cnt_scaled, k.nsc, -(a1s * a2));   // 1e4 * Dn, exact (< 2^53)
     const bool neg = dn4 < 0.0;
     const double x = neg ? ra2 : rr2, y = neg ? rr2 : ra2;
-    const double inv = __builtin_fmax(ra1 * x, rr1 * y);                 // 1 / B  (inf: degenerate)
+    const double inv = max_raw(ra1 * x, rr1 * y);                        // 1 / B  (inf: degenerate)
     const double yd = __builtin_fabs(dn4) * inv;                         // D'  * 10^4
     const double z = dn4 * (rq1s * rq2);
     const double yr = z * dn4;                                           // r^2 * 10^4
     const double kd = __builtin_rint(yd), kr = __builtin_rint(yr);
-    const double hd = __builtin_fma(inv, -k.cd, 0.499999);
-    const double hr = __builtin_fma(__builtin_fabs(z), -k.cr, 0.499999);
-    const bool sure = __builtin_fabs(yd - kd) < hd && __builtin_fabs(yr - kr) < hr &&
-                      __builtin_fmax(yd, yr) < 1e7 && dn4 != 0.0;
+    const double hd = __builtin_fma(inv, k.ncd, 0.499999);
+    const double hr = __builtin_fma(__builtin_fabs(z), k.ncr, 0.499999);
+    // `&`, not `&&`: a short-circuit becomes a branch per pair and the pairs' chains no longer interleave
+    const bool sure = (__builtin_fabs(yd - kd) < hd) & (__builtin_fabs(yr - kr) < hr) & (max_raw(yd, yr) < 1e7) &
+                      (dn4 != 0.0);
     const bool degenerate = inv == __builtin_inf();
     slow = !(sure || degenerate);
     ldx_ld32 o;
@@ -255,5 +264,39 @@ __device__ __forceinline__ ldx_ld32 ld_pair_fast2(double cnt_scaled, const FastC
     o.r_square = degenerate ? -0.0f : vr;
     return o;
 }
+
+// W pairs at once, stage by stage: ld_pair_fast2 for the operand sets (r[k], c[k]), k < W, with the W dependent
+// chains INTERLEAVED by construction.  Left to itself hipcc schedules each pair's ~36 instructions back to back
+// (register pressure beside 128 live accumulators), every fp64 instruction then waits for its predecessor's
+// result, and a lone epilogue wave ran at ~10 cycles per instruction instead of the 4-5 it can issue.  The
+// sched_barriers pin "all W pairs, one stage" as the instruction order.
+#define LDX_STAGE(body)                                  \
+    _Pragma("unroll") for (int t_ = 0; t_ < W; ++t_) { body; } \
+    __builtin_amdgcn_sched_barrier(0);
+
+template <int W>
+__device__ __forceinline__ void ld_multi_fast2(const int (&cnt_scaled)[W], const FastConst &k, const FastRow (&r)[W],
+                                               const FastCol (&c)[W], ldx_ld32 (&out)[W], bool (&slow)[W])
+{
+    double dn4[W], x[W], y[W], inv[W], w[W], z[W], yd[W], yr[W], kd[W], kr[W], hd[W], hr[W], ed[W], er[W], mx[W];
+    bool ok[W], deg[W];
+    __builtin_amdgcn_sched_barrier(0);
+    LDX_STAGE(dn4[t_] = (double)cnt_scaled[t_]; w[t_] = r[t_].a_s * c[t_].a)
+    LDX_STAGE(dn4[t_] = __builtin_fma(dn4[t_], k.nsc, -w[t_]); w[t_] = r[t_].rq_s * c[t_].rq)   // 1e4 * Dn, exact
+    LDX_STAGE(const bool neg = dn4[t_] < 0.0; x[t_] = neg ? c[t_].ra : c[t_].rr; y[t_] = neg ? c[t_].rr : c[t_].ra)
+    LDX_STAGE(x[t_] = r[t_].ra * x[t_]; y[t_] = r[t_].rr * y[t_]; z[t_] = dn4[t_] * w[t_])
+    LDX_STAGE(inv[t_] = max_raw(x[t_], y[t_]); yr[t_] = z[t_] * dn4[t_])                       // 1 / B;  r^2 * 10^4
+    LDX_STAGE(yd[t_] = __builtin_fabs(dn4[t_]) * inv[t_]; kr[t_] = __builtin_rint(yr[t_]);     // D' * 10^4
+              hr[t_] = __builtin_fma(__builtin_fabs(z[t_]), k.ncr, 0.499999))
+    LDX_STAGE(kd[t_] = __builtin_rint(yd[t_]); hd[t_] = __builtin_fma(inv[t_], k.ncd, 0.499999); er[t_] = yr[t_] - kr[t_];
+              mx[t_] = max_raw(yd[t_], yr[t_]))
+    LDX_STAGE(ed[t_] = yd[t_] - kd[t_]; ok[t_] = (__builtin_fabs(er[t_]) < hr[t_]) & (mx[t_] < 1e7) & (dn4[t_] != 0.0);
+              deg[t_] = inv[t_] == __builtin_inf(); kr[t_] = kr[t_] * 1e-4)
+    LDX_STAGE(ok[t_] = ok[t_] & (__builtin_fabs(ed[t_]) < hd[t_]); kd[t_] = kd[t_] * 1e-4)
+    LDX_STAGE(const float vr = (float)kr[t_]; const float vd = (float)kd[t_];   // float32 nearest to k / 10^4
+              out[t_].r_square = deg[t_] ? -0.0f : vr; out[t_].d_prime = deg[t_] ? -0.0f : vd;
+              slow[t_] = !(ok[t_] | deg[t_]))
+}
+#undef LDX_STAGE
 
 }  // namespace ldx

@@ -133,6 +133,13 @@ __host__ __device__ inline uint32_t mfma_pass_base(uint32_t t, uint32_t n_slabs)
 constexpr uint32_t kSchedSlots = 256;
 __device__ uint32_t g_sched[kSchedSlots][2];
 
+// One "matrix pipe token" per physical CU (index from HW_ID / XCC_ID): the two workgroups that share a CU take
+// turns in the K loop, so one's epilogue (VALU) always runs beside the other's K loop (matrix pipe) instead of
+// K loop beside K loop and epilogue beside epilogue (measured ~1.5x the time per pass).  Speed only: the wait
+// is bounded, and a waiter that gives up simply proceeds (and its release re-arms the token).
+constexpr uint32_t kCuTokens = 4096;
+__device__ uint32_t g_cu_token[kCuTokens];
+
 template <bool kRaw, bool kN11>
 __global__ void __launch_bounds__(kMfmaThreads, 2)
 triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ fa, const double *__restrict__ fr,
@@ -203,12 +210,10 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
     uint32_t parity = 0;
     if (tid == 0) tickets[0] = draw();
 
-    // Stagger: the second half of the grid (dispatched onto the CUs' second slots) starts half a period late,
-    // so that one workgroup's epilogue (VALU) runs beside the other's K loop (matrix pipe).  Speed only.
-    const bool late = blockIdx.x >= (gridDim.x + 1) / 2;
-    if ((ablate & 8) == 0 && late && p_end - p_begin >= 2u * gridDim.x) {
-        const uint32_t naps = nchunks / 4 + 8;   // ~ (nchunks * 1024 + 32k) / 2 cycles in naps of 64 * 32
-        for (uint32_t k = 0; k < naps; ++k) __builtin_amdgcn_s_sleep(32);
+    uint32_t *token = nullptr;
+    if (ablate & 32) {   // experiment (tuning builds): measured no better than free-running workgroups
+        const uint32_t hw = __builtin_amdgcn_s_getreg(63492), xcc = __builtin_amdgcn_s_getreg(63508);   // HW_ID, XCC_ID
+        token = &g_cu_token[((xcc & 0xFu) << 8) | ((hw >> 8) & 0xFFu)];   // XCC | SE | SH | CU
     }
 
     uint32_t t_prev = 0xFFFFFFFFu;
@@ -353,6 +358,10 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 dst[0] = d2{r.a_s, r.ra};
                 dst[1] = d2{r.rr, r.rq_s};
             }
+            if (token && tid == 0) {   // the CU's matrix-pipe token (bounded wait; see g_cu_token)
+                uint32_t polls = 0;
+                while (atomicCAS(token, 0u, 1u) != 0u && ++polls < 2048u) __builtin_amdgcn_s_sleep(16);
+            }
             __syncthreads();
             LDX_STAMP(1);
             v4i af0[2], bf0[4], af1[2], bf1[4];
@@ -426,10 +435,14 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
 #undef LDX_BSHARE_1
 
             LDX_STAMP(2);
+            if (token && tid == 0) __hip_atomic_store(token, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // the next pass's ticket: drawn here (after the K loop's hand-counted loads), stored to LDS after the
             // epilogue, so the atomic's latency hides behind it
             uint32_t next_ticket = 0;
             if (tid == 0) next_ticket = draw();
+            // The epilogue wave outranks the SIMD's other wave (in its K loop, matrix-pipe-bound with issue slots
+            // to spare) in instruction arbitration: +2 % at 40k SNPs.
+            if (!(ablate & 16)) __builtin_amdgcn_s_setprio(3);
             if (!active) {   // wave-uniform; inactive waves only helped with B and the barriers
                 if (tid == 0) tickets[parity] = next_ticket;
                 continue;
@@ -438,17 +451,12 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
             //   i = row0 + 32*m + (e & 3) + 8*(e >> 2) + 4*half,  j = 128*t + 32*tt + l32
             typedef double d2 __attribute__((ext_vector_type(2)));
             double fa2[4], fr2[4];     // kRaw: the mirror's column operands
-            FastCol fc[4];             // !kRaw: the fast epilogue's
             double sfa = 0.0, sfr = 0.0, sq = 0.0;
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
                 if (kRaw) {
                     fa2[tt] = fa[t * kSlab + 32u * tt + l32];
                     fr2[tt] = fr[t * kSlab + 32u * tt + l32];
-                } else {
-                    const d2 *cs = reinterpret_cast<const d2 *>(cstat + (32u * tt + l32) * 4u);
-                    const d2 c01 = cs[0], c23 = cs[1];
-                    fc[tt] = FastCol{c01.x, c01.y, c23.x, c23.y};
                 }
             }
             if (kRaw) {   // one coalesced load per statistic for the unit's 64 rows, handed out by shuffles below
@@ -459,77 +467,122 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
             // The e-loop is NOT unrolled: 128 pairs x ~50 instructions would be ~50 KB of straight-line code
             // per wave, most of the instruction cache two CUs share.  acc[..][..][e] with a wave-uniform e
             // is a register-indirect move (s_set_gpr_idx_on), not scratch.
+#ifdef LDX_AB_UNROLL_E
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
             for (int e = 0; e < 16; ++e) {
+                // The eight pairs of this step (two rows x four column tiles) go through the epilogue WITHOUT
+                // branches -- invalid cells (row <= col, pad rows) are computed on whatever the registers hold and
+                // zeroed by a select -- so their eight dependent fp64 chains interleave: beside another wave's K
+                // loop an epilogue gets few issue slots and must not also wait on its own latencies.
+                uint32_t ri[2], cnt[2][4];
+                uint64_t us[2];
+                bool in_range[2], valid[2][4], slow[2][4];
+                ldx_ld32 res[2][4];
+                ldx_ld64 rw[2][4];
+                bool any_slow = false;
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
-                    const uint32_t ri = 32u * m + (e & 3) + 8u * (e >> 2) + 4u * half;   // row inside the unit
-                    const uint32_t i = row0 + ri;
-                    const uint64_t us = vv * 8u + ri / kGroup;   // the small unit this row belongs to
-                    const bool in_range = us >= u_begin && us < u_end;
-                    // The four pairs of this row (one per column tile) go through the epilogue WITHOUT branches --
-                    // invalid cells (row <= col, pad rows) are computed on whatever the registers hold and zeroed
-                    // by a select -- so their four dependent fp64 chains interleave.
-                    uint32_t cnt[4];
-                    ldx_ld32 res[4];
-                    ldx_ld64 rw[4];
-                    bool valid[4], slow[4];
-                    bool any_slow = false;
-                    if (kRaw) {   // parity / debugging output: the op-for-op mirror, unrounded values kept
-                        const double fa1 = __shfl(sfa, (int)ri), fr1 = __shfl(sfr, (int)ri), q1 = __shfl(sq, (int)ri);
+                    ri[m] = 32u * m + (e & 3) + 8u * (e >> 2) + 4u * half;   // row inside the unit
+                    us[m] = vv * 8u + ri[m] / kGroup;                        // the small unit this row belongs to
+                    in_range[m] = us[m] >= u_begin && us[m] < u_end;
+                }
+                if (kRaw) {   // parity / debugging output: the op-for-op mirror, unrounded values kept
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        const uint32_t i = row0 + ri[m];
+                        const double fa1 = __shfl(sfa, (int)ri[m]), fr1 = __shfl(sfr, (int)ri[m]), q1 = __shfl(sq, (int)ri[m]);
 #pragma unroll
                         for (int tt = 0; tt < 4; ++tt) {
                             const uint32_t j = t * kSlab + 32u * tt + l32;
-                            valid[tt] = (i > j) && (i < n_snps);
-                            cnt[tt] = (uint32_t)acc[m][tt][e] >> 3;
-                            const LdRaw lr = ld_epilogue((double)cnt[tt] / n, fa1, fr1, q1, fa2[tt], fr2[tt]);   // calc_ld.py:33
-                            res[tt] = round_pair(lr);
-                            rw[tt] = valid[tt] ? ldx_ld64{lr.rsq, lr.dprime} : ldx_ld64{0.0, 0.0};
-                            slow[tt] = false;
-                        }
-                    } else {
-                        const d2 *rs = reinterpret_cast<const d2 *>(rstat + ri * 4u);   // two addresses per wave: broadcast
-                        const d2 r01 = rs[0], r23 = rs[1];
-#pragma unroll
-                        for (int tt = 0; tt < 4; ++tt) {
-                            const uint32_t j = t * kSlab + 32u * tt + l32;
-                            valid[tt] = (i > j) && (i < n_snps);
-                            const int a8 = acc[m][tt][e];
-                            cnt[tt] = (uint32_t)a8 >> 3;
-                            if (ablate & 1) {   // tuning: no epilogue arithmetic
-                                res[tt] = ldx_ld32{(float)a8, 0.0f};
-                                slow[tt] = false;
-                            } else {
-                                res[tt] = ld_pair_fast2((double)a8, fk, r01.x, r01.y, r23.x, r23.y, fc[tt].a, fc[tt].ra,
-                                                        fc[tt].rr, fc[tt].rq, slow[tt]);
-                                slow[tt] = slow[tt] && valid[tt];
-                                any_slow = any_slow || slow[tt];
-                            }
-                        }
-                        if (__builtin_expect(__any(any_slow), 0)) {   // near a rounding tie, Dn == 0, ...: the exact mirror
-#pragma unroll
-                            for (int tt = 0; tt < 4; ++tt)
-                                if (slow[tt]) {
-                                    const uint32_t j = t * kSlab + 32u * tt + l32;
-                                    res[tt] = ld_pair_mirror((double)cnt[tt] / n, fa[i], fr[i], q[i], fa[j], fr[j]);
-                                }
+                            valid[m][tt] = (i > j) && (i < n_snps);
+                            cnt[m][tt] = (uint32_t)acc[m][tt][e] >> 3;
+                            const LdRaw lr = ld_epilogue((double)cnt[m][tt] / n, fa1, fr1, q1, fa2[tt], fr2[tt]);   // calc_ld.py:33
+                            res[m][tt] = round_pair(lr);
+                            rw[m][tt] = valid[m][tt] ? ldx_ld64{lr.rsq, lr.dprime} : ldx_ld64{0.0, 0.0};
                         }
                     }
-                    if (in_range && !(ablate & 4)) {
+                } else {
+                    // Two chains at a time (the same column for both rows), staged: with 128 live accumulators there is
+                    // room for the operands and temporaries of two interleaved pairs, not four (hipcc then spills
+                    // accumulator tiles); operands come from LDS every step (4 + 8 ds_read_b128 per 16 pairs).
+                    FastRow fr2x[2];
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        const d2 *rs = reinterpret_cast<const d2 *>(rstat + ri[m] * 4u);   // two addresses per wave: broadcast
+                        const d2 r01 = rs[0], r23 = rs[1];
+                        fr2x[m] = FastRow{r01.x, r01.y, r23.x, r23.y};
+                    }
+                    const d2 *cs = reinterpret_cast<const d2 *>(cstat + l32 * 4u);
+                    d2 c01n = cs[0], c23n = cs[1];
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) {
+                        const d2 c01 = c01n, c23 = c23n;
+                        if (tt < 3) {   // the next column's operands: their LDS latency hides behind this column's arithmetic
+                            c01n = cs[(tt + 1) * 64];
+                            c23n = cs[(tt + 1) * 64 + 1];
+                        }
+                        const FastCol fcx[2] = {FastCol{c01.x, c01.y, c23.x, c23.y}, FastCol{c01.x, c01.y, c23.x, c23.y}};
+                        int a8[2];
+                        ldx_ld32 r2[2];
+                        bool s2[2];
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) {
+                            const uint32_t i = row0 + ri[m], j = t * kSlab + 32u * tt + l32;
+                            valid[m][tt] = (i > j) && (i < n_snps);
+#ifdef LDX_AB_STATIC_E   // tuning: no register-indirect accumulator read (results wrong)
+                            a8[m] = acc[m][tt][0] + e;
+#else
+                            a8[m] = acc[m][tt][e];
+#endif
+                            cnt[m][tt] = (uint32_t)a8[m] >> 3;
+                        }
+                        if (ablate & 1) {   // tuning: no epilogue arithmetic
+#pragma unroll
+                            for (int m = 0; m < 2; ++m) {
+                                res[m][tt] = ldx_ld32{(float)a8[m], 0.0f};
+                                slow[m][tt] = false;
+                            }
+                        } else {
+                            ld_multi_fast2<2>(a8, fk, fr2x, fcx, r2, s2);
+#pragma unroll
+                            for (int m = 0; m < 2; ++m) {
+                                res[m][tt] = r2[m];
+                                slow[m][tt] = s2[m] && valid[m][tt];
+                                any_slow = any_slow || slow[m][tt];
+                            }
+                        }
+                    }
+                    if (__builtin_expect(__any(any_slow), 0)) {   // near a rounding tie, Dn == 0, ...: the exact mirror
+#pragma unroll
+                        for (int m = 0; m < 2; ++m)
+#pragma unroll
+                            for (int tt = 0; tt < 4; ++tt)
+                                if (slow[m][tt]) {
+                                    const uint32_t i = row0 + ri[m], j = t * kSlab + 32u * tt + l32;
+                                    res[m][tt] = ld_pair_mirror((double)cnt[m][tt] / n, fa[i], fr[i], q[i], fa[j], fr[j]);
+                                }
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+                    if (in_range[m] && !(ablate & 4)) {
 #pragma unroll
                         for (int tt = 0; tt < 4; ++tt) {
                             const uint32_t jl = 32u * tt + l32;
-                            const size_t o = (size_t)(us - u_begin) * LDX_UNIT_PAIRS + (size_t)(ri % kGroup) * kSlab + jl;
-                            ldx_ld32 w = res[tt];
-                            if (!valid[tt]) w = ldx_ld32{0.0f, 0.0f};
+                            const size_t o = (size_t)(us[m] - u_begin) * LDX_UNIT_PAIRS + (size_t)(ri[m] % kGroup) * kSlab + jl;
+                            ldx_ld32 w = res[m][tt];
+                            if (!valid[m][tt]) w = ldx_ld32{0.0f, 0.0f};
                             out[o] = w;
-                            if (kRaw) raw[o] = rw[tt];
-                            if (kN11) n11[o] = valid[tt] ? cnt[tt] : 0u;
+                            if (kRaw) raw[o] = rw[m][tt];
+                            if (kN11) n11[o] = valid[m][tt] ? cnt[m][tt] : 0u;
                         }
                     }
-                }
             }
             if (tid == 0) tickets[parity] = next_ticket;
+            if (!(ablate & 16)) __builtin_amdgcn_s_setprio(0);
 #ifdef LDX_TUNING
             LDX_STAMP(3);
             ++npass;

@@ -32,4 +32,12 @@ print("K loop cycles per pass:   ", q(k), f" mean={k.mean():.0f}")
 print("epilogue cycles per pass: ", q(e), f" mean={e.mean():.0f}")
 if g:
     g = np.concatenate(g); print("gap between passes:       ", q(g))
-print(f"passes per wave: median {np.median(st[:,3]):.0f}")
+print("passes per wave histogram:", dict(zip(*np.unique(st[:, 3].astype(int), return_counts=True))))
+t0 = st[:, 2].astype(np.int64); tmin = t0.min()
+print(f"wave start spread: p50={np.percentile(t0 - tmin, 50):.0f} max={(t0 - tmin).max():.0f} cycles;  kernel span (first start -> last end): {(st[:, 5].astype(np.int64).max() - tmin)} cycles")
+# per-pass totals by pass index
+for idx in range(int(st[:, 3].max())):
+    sel = st[st[:, 3] > idx]
+    s4 = sel[:, 6 + 4 * idx: 10 + 4 * idx].astype(np.int64)
+    print(f"  pass #{idx}: n={len(sel):5d} start(p50, rel)={np.median(s4[:, 0] - tmin):9.0f}  K={np.median(s4[:, 2] - s4[:, 1]):7.0f}  E={np.median(s4[:, 3] - s4[:, 2]):7.0f}  end(p50)={np.median(s4[:, 3] - tmin):9.0f} end(max)={(s4[:, 3] - tmin).max():9.0f}")
+    if idx >= 5: break
