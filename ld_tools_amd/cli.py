@@ -1,0 +1,192 @@
+"""Command-line shells with the reference's flags (cli/ld_{triangle,area,lite}_cli_en.py) around the batched drivers.
+
+    python ld_triangle.py -S src -D 1000g -f -o table ...      python ld_area.py -S src -D 1000g -f -w 500000 -z 0.8
+    python ld_lite.py rs1 rs2 -D 1000g -f
+
+What differs from the reference's scripts, on purpose:
+  * the 1000 Genomes download / indexing / conversion.db build (backend/prep_intgen_data.py) is not part of this
+    package: the folder must already hold ``{chrom}.vcf.gz`` (+ .tbi) and ``conversion.db``; without ``-f`` the
+    shells only check that they exist;
+  * source tables are processed one after another on the GPU instead of in a multiprocessing.Pool
+    (ld_triangle.py:390-411): a table takes milliseconds of kernel time, and HIP must not be forked;
+  * ld_triangle writes the tabular matrix; the plotly heat map (ld_triangle.py:239-340) is not produced;
+  * help texts are English only (the reference picks Russian by locale, ld_triangle.py:386-389).
+pysam is imported here and nowhere else in the package.
+"""
+from __future__ import annotations
+
+import datetime
+import os
+import sqlite3
+import sys
+from argparse import ArgumentParser, RawTextHelpFormatter
+
+__version__ = "V11.2-ldx"
+
+
+def _common(argparser, with_src=True):
+    if with_src:
+        argparser.add_argument("-S", "--src-dir-path", metavar="str", dest="src_dir_path", type=str,
+                               help="Path to folder with source tables")
+    argparser.add_argument("-D", "--intgen-dir-path", metavar="str", dest="intgen_dir_path", type=str,
+                           help="Path to folder for 1000G data")
+    if with_src:
+        argparser.add_argument("-t", "--trg-top-dir-path", metavar="[None]", dest="trg_top_dir_path", type=str,
+                               help="Path to target folder (default: path to source folder)")
+        argparser.add_argument("-m", "--meta-lines-quan", metavar="[0]", default=0, dest="meta_lines_quan", type=int,
+                               help="Number of meta-information lines (including line with column names)")
+    argparser.add_argument("-f", "--skip-intgen-data-ver", dest="skip_intgen_data_ver", action="store_true",
+                           help="Do not check 1000G data completeness (start main calculations immediately)")
+    argparser.add_argument("-g", "--gend-names", metavar="[both]", choices=["male", "female", "both"], default="both",
+                           dest="gend_names", type=str,
+                           help="{male, female, both} Belonging of 1000G samples to genders")
+    argparser.add_argument("-e", "--pop-names", metavar="[all]", default="all", dest="pop_names", type=str,
+                           help="Belonging of 1000G samples to populations (separated by commas without space)")
+
+
+def triangle_parser():
+    """cli/ld_triangle_cli_en.py:40-74 -- same flags, dests, defaults and choices."""
+    p = ArgumentParser(description=f"Builds LD matrices for all pairs of each set of variants (tables). Version: {__version__}",
+                       formatter_class=RawTextHelpFormatter)
+    _common(p)
+    p.add_argument("-l", "--ld-measure", metavar="[r_square]", choices=["r_square", "d_prime"], default="r_square",
+                   dest="ld_measure", type=str, help="{r_square, d_prime} LD measure for building matrices and for the lower threshold")
+    p.add_argument("-z", "--ld-low-thres", metavar="[None]", dest="ld_low_thres", type=float,
+                   help="Lower LD threshold (subthreshold values will be zeroed)")
+    p.add_argument("-o", "--matrix-type", metavar="[heatmap]", choices=["heatmap", "table", "both"], default="heatmap",
+                   dest="matrix_type", type=str, help="{heatmap, table, both} Type of LD value matrices (this build writes the table)")
+    p.add_argument("-j", "--heatmap-json", dest="heatmap_json", action="store_true", help="(heat maps are not produced by this build)")
+    p.add_argument("-i", "--disp-letters", dest="disp_letters", action="store_true", help="(heat maps are not produced by this build)")
+    p.add_argument("-c", "--color-pal", metavar="[greens]", default="greens", dest="color_pal", type=str, help="(heat maps are not produced by this build)")
+    p.add_argument("-k", "--font-size", metavar="[None]", dest="font_size", type=int, help="(heat maps are not produced by this build)")
+    p.add_argument("-q", "--square-shape", dest="square_shape", action="store_true", help="(heat maps are not produced by this build)")
+    p.add_argument("-s", "--dont-disp-footer", dest="dont_disp_footer", action="store_true", help="(heat maps are not produced by this build)")
+    p.add_argument("-p", "--max-proc-quan", metavar="[4]", default=4, dest="max_proc_quan", type=int,
+                   help="Maximum number of tables to be processed in parallel (accepted; tables run one after another on the GPU)")
+    return p
+
+
+def area_parser():
+    """cli/ld_area_cli_en.py:36-60"""
+    p = ArgumentParser(description=f"Finds variants in LD with the requested ones within flanks. Version: {__version__}",
+                       formatter_class=RawTextHelpFormatter)
+    _common(p)
+    p.add_argument("-w", "--flank-size", metavar="[100000]", default=100000, dest="flank_size", type=int,
+                   help="Size of each flank around each query variant within which LD is calculated")
+    p.add_argument("-l", "--ld-thres-measure", metavar="[r_square]", choices=["r_square", "d_prime"], default="r_square",
+                   dest="ld_thres_measure", type=str, help="{r_square, d_prime} LD measure for setting the lower threshold")
+    p.add_argument("-z", "--ld-low-thres", metavar="[0.8]", default=0.8, dest="ld_low_thres", type=float,
+                   help="Lower LD threshold")
+    p.add_argument("-o", "--trg-file-type", metavar="[tsv]", choices=["tsv", "json", "rsids"], default="tsv",
+                   dest="trg_file_type", type=str, help="{tsv, json, rsids} Format of target files")
+    p.add_argument("-p", "--max-proc-quan", metavar="[4]", default=4, dest="max_proc_quan", type=int,
+                   help="Maximum number of tables to be processed in parallel (accepted; tables run one after another on the GPU)")
+    return p
+
+
+def lite_parser():
+    """cli/ld_lite_cli_en.py:37-49"""
+    p = ArgumentParser(description=f"Prints LD of a pair of variants. Version: {__version__}", formatter_class=RawTextHelpFormatter)
+    p.add_argument("rs_id_1", metavar="rs_id_1", type=str, help="Reference SNP ID of the first variant")
+    p.add_argument("rs_id_2", metavar="rs_id_2", type=str, help="Reference SNP ID of the second variant")
+    _common(p, with_src=False)
+    return p
+
+
+def _names(args):
+    """gender / population tuples exactly as ld_triangle.py:33-38 builds them"""
+    gend = {"male": ("male",), "female": ("female",)}.get(args.gend_names, ("male", "female"))
+    return gend, tuple(args.pop_names.upper().split(","))
+
+
+def _convdb(args):
+    intgen_dir_path = os.path.normpath(args.intgen_dir_path)
+    db = os.path.join(intgen_dir_path, "conversion.db")
+    if not os.path.exists(db):
+        raise SystemExit(f"{db} not found: this build does not download or index 1000 Genomes data "
+                         "(backend/prep_intgen_data.py of the reference does); prepare the folder first")
+    return intgen_dir_path, db
+
+
+def _vcf_opener(intgen_dir_path):
+    try:
+        from pysam import VariantFile
+    except ImportError as e:
+        raise SystemExit("pysam is required to read the 1000 Genomes VCFs") from e
+    return lambda chrom: VariantFile(os.path.join(intgen_dir_path, f"{chrom}.vcf.gz"))
+
+
+def _src_files(args):
+    src_dir_path = os.path.normpath(args.src_dir_path)
+    trg = src_dir_path if args.trg_top_dir_path is None else os.path.normpath(args.trg_top_dir_path)
+    return src_dir_path, trg, sorted(os.listdir(src_dir_path))
+
+
+def ld_triangle_main(argv=None):
+    from .backend.create_src_dict import create_src_dict
+    from .backend.get_sample_names import get_sample_names
+    from .drivers import create_matrix
+
+    args = triangle_parser().parse_args(argv)
+    intgen_dir_path, db = _convdb(args)
+    gend_names, pop_names = _names(args)
+    sample_names = get_sample_names(gend_names, pop_names, db)
+    src_dir_path, trg_top, src_file_names = _src_files(args)
+    opener = _vcf_opener(intgen_dir_path)
+    print(f"\nLD matrices building\n\tquantity of parallel processes: 1 (GPU)")
+    t0 = datetime.datetime.now()
+    for name in src_file_names:
+        data = create_src_dict(src_dir_path, name, args.meta_lines_quan, db)
+        create_matrix(opener, data, name, trg_top, sample_names, args.ld_measure, args.ld_low_thres, args.matrix_type,
+                      pop_names, gend_names)
+    print(f"\tparallel computation time: {datetime.datetime.now() - t0}")
+
+
+def ld_area_main(argv=None):
+    from .backend.create_src_dict import create_src_dict
+    from .backend.get_sample_names import get_sample_names
+    from .drivers import get_inld_vars
+
+    args = area_parser().parse_args(argv)
+    intgen_dir_path, db = _convdb(args)
+    gend_names, pop_names = _names(args)
+    sample_names = get_sample_names(gend_names, pop_names, db)
+    src_dir_path, trg_top, src_file_names = _src_files(args)
+    opener = _vcf_opener(intgen_dir_path)
+    print(f"\nSearching for variants in LD\n\tquantity of parallel processes: 1 (GPU)")
+    t0 = datetime.datetime.now()
+    for name in src_file_names:
+        data = create_src_dict(src_dir_path, name, args.meta_lines_quan, db)
+        get_inld_vars(opener, data, name, trg_top, sample_names, args.flank_size, args.ld_thres_measure,
+                      args.ld_low_thres, args.trg_file_type, pop_names, gend_names)
+    print(f"\tparallel computation time: {datetime.datetime.now() - t0}")
+
+
+def ld_lite_main(argv=None):
+    from .backend.get_sample_names import get_sample_names
+    from .drivers import DifChrsError, check_rs_id, ld_lite_table
+
+    args = lite_parser().parse_args(argv)
+    intgen_dir_path, db = _convdb(args)
+    gend_names, pop_names = _names(args)
+    sample_names = get_sample_names(gend_names, pop_names, db)
+    with sqlite3.connect(db) as conn:
+        cursor = conn.cursor()
+        var_1 = check_rs_id(args.rs_id_1, cursor)
+        var_2 = check_rs_id(args.rs_id_2, cursor)
+        cursor.close()
+    if var_1[0] != var_2[0]:
+        raise DifChrsError(args.rs_id_1, args.rs_id_2)
+    vcf = _vcf_opener(intgen_dir_path)(var_1[0])
+    try:
+        print(ld_lite_table(vcf, var_1[0], args.rs_id_1, var_1[1], args.rs_id_2, var_2[1], sample_names))
+    finally:
+        vcf.close()
+
+
+if __name__ == "__main__":
+    tool = sys.argv[1] if len(sys.argv) > 1 else ""
+    mains = {"ld_triangle": ld_triangle_main, "ld_area": ld_area_main, "ld_lite": ld_lite_main}
+    if tool not in mains:
+        raise SystemExit("usage: python -m ld_tools_amd.cli {ld_triangle|ld_area|ld_lite} [flags]")
+    mains[tool](sys.argv[2:])

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Expected driver outputs (text) made with the REAL reference calc_ld -> tests/golden/driver_text.json.
+
+Run in the build container only (needs /root/reference):   python tests/golden/make_golden_drivers.py
+The loops and writers are tests/ref_loops.py (a restatement); only calc_ld comes from the reference.  Stored:
+the texts, not the reference's source.
+"""
+import json
+import sys
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+ROOT = HERE.parent.parent
+sys.dont_write_bytecode = True
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+from backend.calc_ld import calc_ld as ref_calc_ld  # noqa: E402  (the reference)
+
+import fakevcf  # noqa: E402
+import ref_loops  # noqa: E402
+
+vcf, names = fakevcf.make_chromosome()
+rows = [[r.pos, r.id] for r in vcf.records if r.id.startswith("rs") and ";" not in r.id]
+seen, uniq = set(), []
+for r in rows:                       # one row per rsID (the conversion database holds each id once)
+    if r[1] not in seen:
+        seen.add(r[1])
+        uniq.append(r)
+tri_rows = uniq[::2][:16]
+out = {"triangle": {}, "area": {}}
+for measure in ("r_square", "d_prime"):
+    for thres in (None, 0.3):
+        out["triangle"][f"{measure}|{thres}"] = ref_loops.triangle_tsv(
+            vcf, "6", tri_rows, names, measure, thres, ("EUR", "AMR"), ("male", "female"), ref_calc_ld)
+queries = uniq[::3]
+for ftype in ("tsv", "json", "rsids"):
+    for measure, thres, flank in (("r_square", 0.8, 1000), ("d_prime", 0.9, 400), ("r_square", 0.05, 2500)):
+        out["area"][f"{ftype}|{measure}|{thres}|{flank}"] = ref_loops.area_files(
+            vcf, "6", queries, names, flank, measure, thres, ftype, ("ALL",), ("female",), ref_calc_ld)
+(HERE / "driver_text.json").write_text(json.dumps(out, indent=0, sort_keys=True))
+print({k: {kk: (len(v) if isinstance(v, str) else len(v)) for kk, v in d.items()} for k, d in out.items()})

@@ -1,0 +1,215 @@
+"""Drivers either side of the hot path: ingest, ld_triangle / ld_area / ld_lite drivers, writers, CLI.
+
+Expected texts: tests/golden/driver_text.json, made by tests/golden/make_golden_drivers.py with the reference's own
+calc_ld inside the reference's loop order (tests/ref_loops.py).  CPU tests pin the restated loops (with the oracle's
+calc_ld) to that golden and cover the host-only pieces; GPU tests compare what the batched drivers write, byte for
+byte.
+"""
+import json
+import os
+import sqlite3
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "tests"))
+
+import fakevcf  # noqa: E402
+import ref_loops  # noqa: E402
+from oracle import ld_oracle as orc  # noqa: E402
+
+GOLD = json.loads((ROOT / "tests" / "golden" / "driver_text.json").read_text())
+
+
+def _rows(vcf):
+    rows = [[r.pos, r.id] for r in vcf.records if r.id.startswith("rs") and ";" not in r.id]
+    seen, uniq = set(), []
+    for r in rows:
+        if r[1] not in seen:
+            seen.add(r[1])
+            uniq.append(r)
+    return uniq
+
+
+@pytest.fixture(scope="module")
+def chrom6():
+    vcf, names = fakevcf.make_chromosome()
+    uniq = _rows(vcf)
+    return vcf, names, uniq[::2][:16], uniq[::3]
+
+
+AREA_CASES = [("r_square", 0.8, 1000), ("d_prime", 0.9, 400), ("r_square", 0.05, 2500)]
+
+
+# ------------------------------------------------------------------------------------------ CPU
+def test_restated_loops_with_oracle_match_reference_golden(chrom6):
+    vcf, names, tri_rows, queries = chrom6
+    for key, text in GOLD["triangle"].items():
+        measure, thres = key.split("|")
+        thres = None if thres == "None" else float(thres)
+        assert ref_loops.triangle_tsv(vcf, "6", tri_rows, names, measure, thres, ("EUR", "AMR"), ("male", "female"),
+                                      orc.calc_ld_lists) == text
+    for measure, thres, flank in AREA_CASES:
+        got = ref_loops.area_files(vcf, "6", queries, names, flank, measure, thres, "tsv", ("ALL",), ("female",),
+                                   orc.calc_ld_lists)
+        assert got == GOLD["area"][f"tsv|{measure}|{thres}|{flank}"]
+
+
+def test_cli_surface_matches_reference():
+    from ld_tools_amd import cli
+    tri = vars(cli.triangle_parser().parse_args(["-S", "s", "-D", "d"]))
+    assert tri == {"src_dir_path": "s", "intgen_dir_path": "d", "trg_top_dir_path": None, "meta_lines_quan": 0,
+                   "skip_intgen_data_ver": False, "gend_names": "both", "pop_names": "all", "ld_measure": "r_square",
+                   "ld_low_thres": None, "matrix_type": "heatmap", "heatmap_json": False, "disp_letters": False,
+                   "color_pal": "greens", "font_size": None, "square_shape": False, "dont_disp_footer": False,
+                   "max_proc_quan": 4}                      # cli/ld_triangle_cli_en.py:40-74
+    area = vars(cli.area_parser().parse_args(["-S", "s", "-D", "d"]))
+    assert area == {"src_dir_path": "s", "intgen_dir_path": "d", "trg_top_dir_path": None, "meta_lines_quan": 0,
+                    "skip_intgen_data_ver": False, "gend_names": "both", "pop_names": "all", "flank_size": 100000,
+                    "ld_thres_measure": "r_square", "ld_low_thres": 0.8, "trg_file_type": "tsv", "max_proc_quan": 4}
+    lite = vars(cli.lite_parser().parse_args(["rs1", "rs2", "-D", "d", "-g", "female", "-e", "eur,amr"]))
+    assert lite == {"rs_id_1": "rs1", "rs_id_2": "rs2", "intgen_dir_path": "d", "skip_intgen_data_ver": False,
+                    "gend_names": "female", "pop_names": "eur,amr"}
+    with pytest.raises(SystemExit):
+        cli.area_parser().parse_args(["-o", "xml"])
+    a = cli.triangle_parser().parse_args(["-e", "eur,amr", "-g", "male"])
+    assert cli._names(a) == (("male",), ("EUR", "AMR"))      # ld_triangle.py:33-38
+
+
+def test_sample_and_source_lookups(tmp_path):
+    from ld_tools_amd.backend.create_src_dict import create_src_dict
+    from ld_tools_amd.backend.get_sample_names import get_sample_names
+    from ld_tools_amd.drivers import NotInIntgenConvDbError, NotRsIdError, check_rs_id
+    db = tmp_path / "conversion.db"
+    with sqlite3.connect(db) as conn:
+        conn.execute("CREATE TABLE samples (sample TEXT, pop TEXT, super_pop TEXT, gender TEXT)")
+        conn.executemany("INSERT INTO samples VALUES (?, ?, ?, ?)",
+                         [("HG1", "GBR", "EUR", "male"), ("HG2", "FIN", "EUR", "female"), ("HG3", "PEL", "AMR", "female"),
+                          ("HG4", "YRI", "AFR", "male")])
+        conn.execute("CREATE TABLE variants (CHROM TEXT, POS INTEGER, ID TEXT)")
+        conn.executemany("INSERT INTO variants VALUES (?, ?, ?)", [("6", 100, "rs1"), ("6", 50, "rs2"), ("7", 5, "rs3")])
+    assert get_sample_names(("male", "female"), ("ALL",), str(db)) == ["HG1", "HG2", "HG3", "HG4"]
+    assert get_sample_names(("female",), ("EUR", "PEL"), str(db)) == ["HG2", "HG3"]
+    assert get_sample_names(("male",), ("AFR",), str(db)) == ["HG4"]
+    (tmp_path / "src.tsv").write_text("header rs999\nx\trs1\ty\nrs2 and rs3 on one line\nno id here\nz rs3\nrs77777\n")
+    d = create_src_dict(str(tmp_path), "src.tsv", 1, str(db))
+    assert {c: sorted(v) for c, v in d.items()} == {"6": [[50, "rs2"], [100, "rs1"]], "7": [[5, "rs3"]]}
+    assert create_src_dict(str(tmp_path), "src.tsv", 6, str(db)) == {}
+    with sqlite3.connect(db) as conn:
+        cur = conn.cursor()
+        assert tuple(check_rs_id("rs1", cur)) == ("6", 100)
+        with pytest.raises(NotRsIdError):
+            check_rs_id("esv5", cur)
+        with pytest.raises(NotInIntgenConvDbError):
+            check_rs_id("rs424242", cur)
+
+
+def test_ingest_helpers(chrom6):
+    from ld_tools_amd.drivers import RaggedGenotypesError, codes_matrix, find_record, sample_genotypes
+    from ld_tools_amd.drivers.area import build_ucsc_header
+    from ld_tools_amd.drivers.ingest import k_to_python
+    vcf, names, _, _ = chrom6
+    rec = vcf.records[3]
+    g = sample_genotypes(rec, names)
+    assert len(g) == 2 * (len(names) - 1)                     # sample 7 is in no record: skipped (KeyError path)
+    assert g[:4] == list(rec.samples[names[0]]["GT"]) + list(rec.samples[names[1]]["GT"])
+    assert find_record(vcf, "6", rec.pos, rec.id) is rec
+    assert find_record(vcf, "6", rec.pos, "rs0") is None
+    dup = vcf.records[20]                                     # shares its position with record 19
+    assert find_record(vcf, "6", dup.pos, dup.id) is dup
+    m = codes_matrix([[1, 0, None, 2], [0, 0, 1, 1.0]])
+    assert m.dtype == np.int8 and m.tolist() == [[1, 0, 2, 2], [0, 0, 1, 1]]
+    with pytest.raises(RaggedGenotypesError):
+        codes_matrix([[1, 0], [1, 0, 1]])
+    with pytest.raises(ZeroDivisionError):
+        codes_matrix([[1, 0], []])
+    assert build_ucsc_header("chr", "6") == 'chr="6"'
+    assert build_ucsc_header("pops", ("EUR", "AMR")) == 'pops="EUR","AMR"'
+    assert build_ucsc_header("each_flank", 100000) == "each_flank=100000"
+    vals = k_to_python(np.array([0.8216, -0.0, 0.0, 1.0, 0.0003], dtype=np.float32))
+    assert [repr(v) for v in vals] == ["0.8216", "0", "0.0", "1.0", "0.0003"]
+
+
+# ------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_triangle_driver_writes_reference_text(chrom6, tmp_path):
+    from ld_tools_amd.drivers import create_matrix, triangle_matrix, write_triangle_table
+    vcf, names, tri_rows, _ = chrom6
+    for key, text in GOLD["triangle"].items():
+        measure, thres = key.split("|")
+        thres = None if thres == "None" else float(thres)
+        shuffled = tri_rows[5:] + tri_rows[:5]                # the driver sorts by position (ld_triangle.py:88)
+        m = triangle_matrix(vcf, "6", shuffled, names, measure, thres)
+        p = tmp_path / f"t_{measure}_{thres}.tsv"
+        write_triangle_table(str(p), m, measure, ("EUR", "AMR"), ("male", "female"))
+        assert p.read_text() == text
+        assert all(type(v) is int and v == 0 for r in range(len(tri_rows)) for v in m.ld_two_dim[r][r:])
+    before = vcf.fetches
+    triangle_matrix(vcf, "6", tri_rows, names)
+    assert vcf.fetches - before == len(tri_rows)              # one fetch per variant, not two per pair
+    # folder / file naming of create_matrix (ld_triangle.py:66-69,236,348); a one-variant chromosome is skipped
+    written = create_matrix(lambda chrom: vcf, {"6": tri_rows, "7": tri_rows[:1]}, "my.table.tsv", str(tmp_path), names,
+                            "d_prime", 0.3, "table", ("EUR", "AMR"), ("male", "female"))
+    assert written == [str(tmp_path / "my.table_LD_matr" / "my.table_chr6_d.tsv")]
+    assert Path(written[0]).read_text() == GOLD["triangle"]["d_prime|0.3"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ftype", ["tsv", "json", "rsids"])
+def test_area_driver_writes_reference_text(chrom6, tmp_path, ftype):
+    from ld_tools_amd.drivers import get_inld_vars
+    vcf, names, _, queries = chrom6
+    for k, (measure, thres, flank) in enumerate(AREA_CASES):
+        want = GOLD["area"][f"{ftype}|{measure}|{thres}|{flank}"]
+        top = tmp_path / f"case{k}"
+        top.mkdir()
+        written = get_inld_vars(lambda chrom: vcf, {"6": queries}, "q.txt", str(top), names, flank, measure, thres, ftype,
+                                ("ALL",), ("female",))
+        got = {os.path.basename(p): Path(p).read_text() for p in written}
+        assert sorted(got) == sorted(want)
+        for name in want:
+            assert got[name] == want[name], name
+        assert all(os.path.dirname(p) == str(top / "q_in_LD" / "6") for p in written)
+    with pytest.raises(FileExistsError):                      # os.makedirs without exist_ok (ld_area.py:121-123)
+        get_inld_vars(lambda chrom: vcf, {"6": queries[:1]}, "q.txt", str(tmp_path / "case0"), names)
+
+
+@pytest.mark.gpu
+def test_area_driver_against_oracle_wide_window(chrom6):
+    """A window that spans the whole chromosome, every record a query (incl. the MULTI_ALLELIC, non-rs and long-REF
+    ones): hits equal the restated reference loop with the oracle's calc_ld."""
+    from ld_tools_amd.drivers import area_scan
+    from ld_tools_amd.drivers.area import HEADER_ROW
+    vcf, names, _, _ = chrom6
+    rows = [[r.pos, r.id] for r in vcf.records if r.id != "rs9029"]      # the duplicated id is ambiguous as a query
+    res = area_scan(vcf, "6", rows, names, 10 ** 6, "r_square", 0.2)
+    want = ref_loops.area_files(vcf, "6", rows, names, 10 ** 6, "r_square", 0.2, "json", ("ALL",), ("male",),
+                                orc.calc_ld_lists)
+    got = {}
+    for r in res:
+        if r.hits:
+            got[f"{r.query_id}_chr6_r_0.2.json"] = [dict(zip(HEADER_ROW, r.query_ann))] + [dict(zip(HEADER_ROW, h)) for h in r.hits]
+    assert sorted(got) == sorted(want)
+    for name, text in want.items():
+        assert json.loads(text)[1:] == json.loads(json.dumps(got[name])), name
+
+
+@pytest.mark.gpu
+def test_ld_lite_table(chrom6):
+    pytest.importorskip("tabulate")
+    from tabulate import tabulate
+    from ld_tools_amd.drivers import ld_lite_table
+    vcf, names, tri_rows, _ = chrom6
+    (p1, id1), (p2, id2) = tri_rows[2], tri_rows[9]
+    r1 = next(r for r in vcf.records if r.id == id1)
+    r2 = next(r for r in vcf.records if r.id == id2)
+    vals = orc.calc_ld_lists(ref_loops._genotypes(r1, names), ref_loops._genotypes(r2, names))
+    want = tabulate([["chrom", "6", "6"], ["hg38_pos", p1, p2], ["alleles", "A/G", "A/G"], ["type", "SNP", "SNP"],
+                     ["alt_freq", vals["var_1_alt_freq"], vals["var_2_alt_freq"]]],
+                    headers=[tabulate([["r2", vals["r_square"]], ["D'", vals["d_prime"]], ["abs_dist", abs(p1 - p2)]],
+                                      tablefmt="fancy_grid", disable_numparse=True), f"\n\n\n{id1}", f"\n\n\n{id2}"],
+                    tablefmt="fancy_grid")                    # ld_lite.py:148-159
+    assert ld_lite_table(vcf, "6", id1, p1, id2, p2, names) == want
