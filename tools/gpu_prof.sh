@@ -15,7 +15,7 @@ timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fe
 echo "[pmc fetch] exit $?"
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 bench.py $ARGS > "$OUT/bench_pmc_write.log" 2>&1
 echo "[pmc write] exit $?"
-timeout -k 10 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_sq" -- python3 bench.py $ARGS > "$OUT/bench_pmc_sq.log" 2>&1
+timeout -k 10 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_sq" -- python3 bench.py $ARGS > "$OUT/bench_pmc_sq.log" 2>&1
 echo "[pmc sq] exit $?"
 find "$OUT" -name "*.csv" | head -40
 python3 tools/prof_summary.py "$OUT" > "$OUT/summary.txt" 2>&1
