@@ -216,6 +216,13 @@ __device__ __forceinline__ double max_raw(double a, double b)
     return r;
 }
 
+// true iff the SNP is neither monomorphic nor carries missing codes: a > 0, r > 0, a + r == n
+__device__ __forceinline__ bool fast_ordinary(double fa, double fr, double n)
+{
+    const double a = __builtin_rint(fa * n), r = __builtin_rint(fr * n);
+    return a > 0.0 && r > 0.0 && a + r == n;
+}
+
 __device__ __forceinline__ FastRow fast_row(double fa, double fr, double n)
 {
     const double a = __builtin_rint(fa * n), r = __builtin_rint(fr * n);   // the counts back from a/n, r/n: exact
@@ -274,7 +281,10 @@ __device__ __forceinline__ ldx_ld32 ld_pair_fast2(double cnt_scaled, const FastC
     _Pragma("unroll") for (int t_ = 0; t_ < W; ++t_) { body; } \
     __builtin_amdgcn_sched_barrier(0);
 
-template <int W>
+// kClean: the caller has established that no operand is degenerate (every count > 0) and that no SNP has missing
+// codes (a + r == n, hence D' <= 1 and r^2 <= 1 up to rounding): the inf test, the int-0 selects and the y < 1e7
+// guard are dropped.
+template <int W, bool kClean = false>
 __device__ __forceinline__ void ld_multi_fast2(const int (&cnt_scaled)[W], const FastConst &k, const FastRow (&r)[W],
                                                const FastCol (&c)[W], ldx_ld32 (&out)[W], bool (&slow)[W])
 {
@@ -289,13 +299,15 @@ __device__ __forceinline__ void ld_multi_fast2(const int (&cnt_scaled)[W], const
     LDX_STAGE(yd[t_] = __builtin_fabs(dn4[t_]) * inv[t_]; kr[t_] = __builtin_rint(yr[t_]);     // D' * 10^4
               hr[t_] = __builtin_fma(__builtin_fabs(z[t_]), k.ncr, 0.499999))
     LDX_STAGE(kd[t_] = __builtin_rint(yd[t_]); hd[t_] = __builtin_fma(inv[t_], k.ncd, 0.499999); er[t_] = yr[t_] - kr[t_];
-              mx[t_] = max_raw(yd[t_], yr[t_]))
-    LDX_STAGE(ed[t_] = yd[t_] - kd[t_]; ok[t_] = (__builtin_fabs(er[t_]) < hr[t_]) & (mx[t_] < 1e7) & (dn4[t_] != 0.0);
-              deg[t_] = inv[t_] == __builtin_inf(); kr[t_] = kr[t_] * 1e-4)
+              if (!kClean) mx[t_] = max_raw(yd[t_], yr[t_]))
+    LDX_STAGE(ed[t_] = yd[t_] - kd[t_]; ok[t_] = (__builtin_fabs(er[t_]) < hr[t_]) & (dn4[t_] != 0.0);
+              if (!kClean) { ok[t_] = ok[t_] & (mx[t_] < 1e7); deg[t_] = inv[t_] == __builtin_inf(); }
+              kr[t_] = kr[t_] * 1e-4)
     LDX_STAGE(ok[t_] = ok[t_] & (__builtin_fabs(ed[t_]) < hd[t_]); kd[t_] = kd[t_] * 1e-4)
     LDX_STAGE(const float vr = (float)kr[t_]; const float vd = (float)kd[t_];   // float32 nearest to k / 10^4
-              out[t_].r_square = deg[t_] ? -0.0f : vr; out[t_].d_prime = deg[t_] ? -0.0f : vd;
-              slow[t_] = !(ok[t_] | deg[t_]))
+              if (kClean) { out[t_].r_square = vr; out[t_].d_prime = vd; slow[t_] = !ok[t_]; }
+              else { out[t_].r_square = deg[t_] ? -0.0f : vr; out[t_].d_prime = deg[t_] ? -0.0f : vd;
+                     slow[t_] = !(ok[t_] | deg[t_]); })
 }
 #undef LDX_STAGE
 

@@ -26,6 +26,7 @@
 #include <stdlib.h>
 
 #include <atomic>
+#include <type_traits>
 
 #include "ldx_common.h"
 #include "ldx_tile.h"
@@ -51,6 +52,9 @@ __device__ __forceinline__ void gload8(v2u &dst, const uint2 *p)
     asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(p));
 }
 
+#ifndef LDX_VALU_PER_MFMA
+#define LDX_VALU_PER_MFMA 5   // K loop: VALU slots scheduled behind each MFMA (a step has ~28 VALU for its 8 MFMAs; 5 measured better than 3 or 4)
+#endif
 constexpr int kMfmaWaves = 4;   // waves per workgroup; two workgroups per CU
 constexpr int kMfmaThreads = kMfmaWaves * 64;
 constexpr uint32_t kRows64 = 64;              // i-rows per wave unit
@@ -104,6 +108,23 @@ __device__ __forceinline__ v4i expand16_a(uint32_t word, uint32_t sel0, uint32_t
 #define LDX_AB_CHUNK(c) ((c) & 0u)
 #else
 #define LDX_AB_CHUNK(c) (c)
+#endif
+
+// In-chunk stamps (build with -DLDX_CHUNK_STAMPS on top of -DLDX_TUNING): s_memtime at six points of ONE chunk
+// (index LDX_CHUNK_STAMPS) of a wave's second pass, kept in SGPRs and written after the K loop.  Issued by
+// inline asm so that hipcc does not drain lgkmcnt for them; an outstanding s_memtime only makes the compiler's
+// own lgkmcnt waits more conservative.
+#ifdef LDX_CHUNK_STAMPS
+#define LDX_CSTAMP(k)                                                                  \
+    if (c_ == (uint32_t)(LDX_CHUNK_STAMPS) && npass == 1) asm volatile("s_memtime %0" : "=s"(cst[k]));
+#else
+#define LDX_CSTAMP(k)
+#endif
+
+#ifdef LDX_AB_NOLOADS   // tuning: the K loop without its global loads (results wrong)
+#define LDX_AB_LOADS(...) (void)c3;
+#else
+#define LDX_AB_LOADS(...) __VA_ARGS__
 #endif
 
 __device__ __forceinline__ uint32_t word_of(const uint4 &v, int w)
@@ -206,6 +227,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
     // beside epilogue) take ~1.5x as long per pass as two in antiphase, and with an equal static share the
     // slowest pair set the kernel time (max wave lifetime 826k cycles against a median of 533k at 10k SNPs).
     uint32_t *tickets = reinterpret_cast<uint32_t *>(cstat + kSlab * 4u + kMfmaWaves * (kRows64 * 4u));   // [2]
+    uint32_t *cols_odd = tickets + 2;   // [2]: per wave of the column stagers, != 0 if one of its columns is not "ordinary"
     auto draw = [&]() { return atomicAdd(&sched[0], 1u); };
     uint32_t parity = 0;
     if (tid == 0) tickets[0] = draw();
@@ -267,8 +289,10 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
 
             // ---- K loop, software-pipelined at K-step (32 haplotypes) granularity -------------------------
             // During the 8 MFMAs of step s the wave (i) has the B fragments of step s+1 in flight from LDS,
-            // (ii) expands the A fragments of step s+1 and (iii) a quarter of its share of the NEXT chunk's
-            // B image.  One workgroup barrier per chunk, placed before the last K-step of the chunk: by then
+            // (ii) expands the A fragments of step s+1 and (iii) a quarter of its share of a later chunk's
+            // B image (steps 0-2: quarters 1-3 of chunk c+1; step 3, after the barrier: quarter 0 of chunk c+2 into
+            // the buffer chunk c just vacated) -- 28 VALU + 1 ds_write_b128 in EVERY step: a step hides ~28 VALU
+            // behind its 8 MFMAs and pays ~7 cycles for each one beyond (tools/probes/steprate.hip).  One workgroup barrier per chunk, placed before the last K-step of the chunk: by then
             // every wave has written its share of chunk c+1 (steps 0..1) and issued its last read of chunk c
             // (the prefetch of step 3, done in step 2), so after it the fragments of (c+1, step 0) can be
             // prefetched and the buffer of chunk c may be overwritten by chunk c+2.  sched_barrier(0) between
@@ -293,7 +317,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                         acc[m][tt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[m], bf[tt], acc[m][tt], 0, 0, 0);
 #endif
             };
-            auto interleave = [&]() {   // 8 x {1 MFMA, 5 VALU}: the VALU work of a step hides behind its MFMAs
+            auto interleave = [&]() {   // 8 x {1 MFMA, up to 5 VALU}: the VALU work of a step hides behind its MFMAs
                 // the next step's four B-fragment reads go FIRST: a whole step (256 cycles) of cover for the LDS
                 // latency; left to itself hipcc sinks them to the end of the step and the next step's first
                 // MFMAs wait on lgkmcnt
@@ -301,7 +325,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, LDX_VALU_PER_MFMA, 0);
                 }
             };
             auto lds_barrier = [&]() {   // LDS-only barrier: no vmcnt(0), the global prefetches stay in flight
@@ -341,11 +365,17 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 d0[1] = expand16(w0.x >> 16);
                 d0[2] = expand16(w0.y);
                 d0[3] = expand16(w0.y >> 16);
+                // quarter 0 of chunk 1 -> buffer 1 (in the loop it is written during step 3 of the chunk before)
+                *reinterpret_cast<v4i *>(bexp + kBBuf + b_off) = expand16(br[1].x);
             }
+            bool rows_ordinary = false;
             if (!kRaw) {   // epilogue operands -> LDS (every wave is past its previous epilogue: barrier above)
                 if (new_tile && tid < kSlab) {
                     const uint32_t j = t * kSlab + tid;
                     const FastCol c = fast_col(fa[j], fr[j], n);
+                    const bool odd = !fast_ordinary(fa[j], fr[j], n);
+                    if (lane == 0) cols_odd[wave] = 0u;
+                    if (__any(odd) && lane == 0) cols_odd[wave] = 1u;
                     typedef double d2 __attribute__((ext_vector_type(2)));
                     d2 *dst = reinterpret_cast<d2 *>(cstat + tid * 4u);
                     dst[0] = d2{c.a, c.ra};
@@ -353,6 +383,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 }
                 const uint32_t i = row0 + lane;
                 const FastRow r = fast_row(fa[i], fr[i], n);
+                rows_ordinary = __all(fast_ordinary(fa[i], fr[i], n));
                 typedef double d2 __attribute__((ext_vector_type(2)));
                 d2 *dst = reinterpret_cast<d2 *>(rstat + lane * 4u);
                 dst[0] = d2{r.a_s, r.ra};
@@ -363,6 +394,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 while (atomicCAS(token, 0u, 1u) != 0u && ++polls < 2048u) __builtin_amdgcn_s_sleep(16);
             }
             __syncthreads();
+            if (ablate & 256) __builtin_amdgcn_s_setprio(3);   // experiment: the K-loop wave outranks instead
             LDX_STAMP(1);
             v4i af0[2], bf0[4], af1[2], bf1[4];
             read_bf(bf0, bexp, 0);
@@ -370,6 +402,9 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
             for (int m = 0; m < 2; ++m) af0[m] = EXPAND_A(ar[0][m].x);
 
             const uint32_t nch_run = (ablate & 2) ? 1u : nchunks;
+#ifdef LDX_CHUNK_STAMPS
+            unsigned long long cst[6] = {0, 0, 0, 0, 0, 0};
+#endif
             // one chunk: ring slot CUR holds its A words, slot NXT the next chunk's (A words and B bits),
             // slot FAR receives chunk c+2
 #define LDX_CHUNK(CUR, NXT, FAR, cc)                                                                               \
@@ -379,48 +414,56 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 unsigned char *wr = bexp + ((c_ + 1u) & 1u) * kBBuf;                                               \
                 v4i *bdst = reinterpret_cast<v4i *>(wr + b_off);                                                   \
                 const uint32_t c3 = LDX_AB_CHUNK(clampc(c_ + 2u));                                                 \
+                LDX_CSTAMP(0)                                                                                      \
                 /* loads of chunk c+2, B bits FIRST (vmcnt counts in issue order).  In flight now, oldest first: */ \
                 /* chunk c+1's {B, A, A} and this batch's {B, A, A}; step 0 needs the former B: 5 may stay */       \
-                gload8(br[FAR], bsrc + (size_t)c3 * kBStride);                                                     \
+                LDX_AB_LOADS(gload8(br[FAR], bsrc + (size_t)c3 * kBStride);                                         \
                 {                                                                                                  \
                     const v4u *src_ = reinterpret_cast<const v4u *>(ai + (size_t)c3 * kSlab);                      \
                     gload16(ar[FAR][0], src_);                                                                     \
                     gload16_512(ar[FAR][1], src_);                                                                 \
-                }                                                                                                  \
+                })                                                                                                 \
                 asm volatile("s_waitcnt vmcnt(5)");                                                                \
                 asm volatile("" : "+v"(br[NXT]));                                                                  \
-                /* step 0: MFMAs of (c,0); prepare (c,1); first half of this thread's share of B chunk c+1 */     \
+                /* step 0: MFMAs of (c,0); prepare (c,1); quarter 1 of this thread's share of B chunk c+1 */      \
                 read_bf(bf1, rd, 1);                                                                               \
                 _Pragma("unroll") for (int m = 0; m < 2; ++m) af1[m] = EXPAND_A(ar[CUR][m].y);               \
-                LDX_BSHARE_0(br[NXT]);                                                                             \
+                bdst[1] = EXPAND_B(br[NXT].x >> 16);                                                               \
                 mma8(af0, bf0);                                                                                    \
                 interleave();                                                                                      \
                 __builtin_amdgcn_sched_barrier(0);                                                                 \
-                /* step 1: MFMAs of (c,1); prepare (c,2); second half of the B share */                           \
+                LDX_CSTAMP(1)                                                                                      \
+                /* step 1: MFMAs of (c,1); prepare (c,2); quarter 2 of the B share */                             \
                 read_bf(bf0, rd, 2);                                                                               \
                 _Pragma("unroll") for (int m = 0; m < 2; ++m) af0[m] = EXPAND_A(ar[CUR][m].z);               \
-                LDX_BSHARE_1(br[NXT]);                                                                             \
+                bdst[2] = EXPAND_B(br[NXT].y);                                                                     \
                 mma8(af1, bf1);                                                                                    \
                 interleave();                                                                                      \
                 __builtin_amdgcn_sched_barrier(0);                                                                 \
-                /* step 2: MFMAs of (c,2); prepare (c,3) */                                                       \
+                LDX_CSTAMP(2)                                                                                      \
+                /* step 2: MFMAs of (c,2); prepare (c,3); quarter 3 of the B share */                             \
                 read_bf(bf1, rd, 3);                                                                               \
                 _Pragma("unroll") for (int m = 0; m < 2; ++m) af1[m] = EXPAND_A(ar[CUR][m].w);               \
+                bdst[3] = EXPAND_B(br[NXT].y >> 16);                                                               \
                 mma8(af0, bf0);                                                                                    \
                 interleave();                                                                                      \
+                __builtin_amdgcn_sched_barrier(0);                                                                 \
+                LDX_CSTAMP(3)                                                                                      \
                 lds_barrier(); /* chunk c+1 complete in `wr`; nobody reads `rd` any more */                       \
+                LDX_CSTAMP(4)                                                                                      \
                 /* step 3: MFMAs of (c,3); prepare (c+1,0) from the other buffer and the next A chunk, whose */   \
-                /* words must have landed: only this chunk's batch of 3 may still be in flight */                 \
-                asm volatile("s_waitcnt vmcnt(3)");                                                                \
-                asm volatile("" : "+v"(ar[NXT][0]), "+v"(ar[NXT][1]));                                             \
+                /* words must have landed; quarter 0 of the B share of chunk c+2 goes into the buffer of chunk c, */ \
+                /* which nobody reads any more.  Only this chunk's two A loads may still be in flight. */           \
+                asm volatile("s_waitcnt vmcnt(2)");                                                                \
+                asm volatile("" : "+v"(ar[NXT][0]), "+v"(ar[NXT][1]), "+v"(br[FAR]));                              \
                 read_bf(bf0, wr, 0);                                                                               \
                 _Pragma("unroll") for (int m = 0; m < 2; ++m) af0[m] = EXPAND_A(ar[NXT][m].x);               \
+                *reinterpret_cast<v4i *>(bexp + (c_ & 1u) * kBBuf + b_off) = EXPAND_B(br[FAR].x);                  \
                 mma8(af1, bf1);                                                                                    \
                 interleave();                                                                                      \
                 __builtin_amdgcn_sched_barrier(0);                                                                 \
+                LDX_CSTAMP(5)                                                                                      \
             }
-#define LDX_BSHARE_0(bits) bdst[0] = EXPAND_B((bits).x); bdst[1] = EXPAND_B((bits).x >> 16)
-#define LDX_BSHARE_1(bits) bdst[2] = EXPAND_B((bits).y); bdst[3] = EXPAND_B((bits).y >> 16)
             for (uint32_t c = 0; c < nch_run; c += 3) {   // block-uniform guards: every wave reaches every barrier
                 LDX_CHUNK(0, 1, 2, c)
                 if (c + 1 < nch_run) LDX_CHUNK(1, 2, 0, c + 1)
@@ -431,9 +474,13 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
             asm volatile("s_waitcnt vmcnt(0)");
             asm volatile("" : "+v"(ar[0][0]), "+v"(ar[0][1]), "+v"(ar[1][0]), "+v"(ar[1][1]), "+v"(ar[2][0]), "+v"(ar[2][1]),
                          "+v"(br[0]), "+v"(br[1]), "+v"(br[2]));
-#undef LDX_BSHARE_0
-#undef LDX_BSHARE_1
 
+            if (ablate & 256) __builtin_amdgcn_s_setprio(0);
+#ifdef LDX_CHUNK_STAMPS
+            asm volatile("s_waitcnt lgkmcnt(0)");
+            if (my_stamps && lane == 0 && npass == 1)
+                for (int k = 0; k < 6; ++k) my_stamps[6 + 4 * (kStampPasses - 2) + k] = cst[k];   // slots of passes 38, 39
+#endif
             LDX_STAMP(2);
             if (token && tid == 0) __hip_atomic_store(token, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // the next pass's ticket: drawn here (after the K loop's hand-counted loads), stored to LDS after the
@@ -464,6 +511,11 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 sfr = fr[row0 + lane];
                 sq = q[row0 + lane];
             }
+            // Two variants of the loop, chosen per wave and pass: the general one, and a "clean" one for units that
+            // lie wholly below the diagonal, inside the panel and inside [u_begin, u_end), whose 64 rows and 128
+            // columns are all ordinary SNPs (polymorphic, no missing codes): no validity tests and selects, no
+            // degenerate handling, no magnitude guard -- ~10 of 43 VALU instructions per pair less.
+            auto epilogue = [&](auto clean_c) {
             // The e-loop is NOT unrolled: 128 pairs x ~50 instructions would be ~50 KB of straight-line code
             // per wave, most of the instruction cache two CUs share.  acc[..][..][e] with a wave-uniform e
             // is a register-indirect move (s_set_gpr_idx_on), not scratch.
@@ -473,6 +525,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
 #pragma unroll 1
 #endif
             for (int e = 0; e < 16; ++e) {
+                constexpr bool kClean = decltype(clean_c)::value;
                 // The eight pairs of this step (two rows x four column tiles) go through the epilogue WITHOUT
                 // branches -- invalid cells (row <= col, pad rows) are computed on whatever the registers hold and
                 // zeroed by a select -- so their eight dependent fp64 chains interleave: beside another wave's K
@@ -487,7 +540,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 for (int m = 0; m < 2; ++m) {
                     ri[m] = 32u * m + (e & 3) + 8u * (e >> 2) + 4u * half;   // row inside the unit
                     us[m] = vv * 8u + ri[m] / kGroup;                        // the small unit this row belongs to
-                    in_range[m] = us[m] >= u_begin && us[m] < u_end;
+                    in_range[m] = kClean || (us[m] >= u_begin && us[m] < u_end);
                 }
                 if (kRaw) {   // parity / debugging output: the op-for-op mirror, unrounded values kept
 #pragma unroll
@@ -531,7 +584,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
 #pragma unroll
                         for (int m = 0; m < 2; ++m) {
                             const uint32_t i = row0 + ri[m], j = t * kSlab + 32u * tt + l32;
-                            valid[m][tt] = (i > j) && (i < n_snps);
+                            valid[m][tt] = kClean || ((i > j) && (i < n_snps));
 #ifdef LDX_AB_STATIC_E   // tuning: no register-indirect accumulator read (results wrong)
                             a8[m] = acc[m][tt][0] + e;
 #else
@@ -546,7 +599,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                                 slow[m][tt] = false;
                             }
                         } else {
-                            ld_multi_fast2<2>(a8, fk, fr2x, fcx, r2, s2);
+                            ld_multi_fast2<2, kClean>(a8, fk, fr2x, fcx, r2, s2);
 #pragma unroll
                             for (int m = 0; m < 2; ++m) {
                                 res[m][tt] = r2[m];
@@ -574,13 +627,19 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                             const uint32_t jl = 32u * tt + l32;
                             const size_t o = (size_t)(us[m] - u_begin) * LDX_UNIT_PAIRS + (size_t)(ri[m] % kGroup) * kSlab + jl;
                             ldx_ld32 w = res[m][tt];
-                            if (!valid[m][tt]) w = ldx_ld32{0.0f, 0.0f};
+                            if (!kClean && !valid[m][tt]) w = ldx_ld32{0.0f, 0.0f};
                             out[o] = w;
                             if (kRaw) raw[o] = rw[m][tt];
                             if (kN11) n11[o] = valid[m][tt] ? cnt[m][tt] : 0u;
                         }
                     }
             }
+            };
+            const bool clean = !kRaw && rows_ordinary && (cols_odd[0] | cols_odd[1]) == 0u &&
+                               row0 >= (t + 1u) * kSlab && row0 + kRows64 <= n_snps && (t + 1u) * kSlab <= n_snps &&
+                               vv * 8u >= u_begin && vv * 8u + 8u <= u_end;
+            if (clean && !(ablate & 512)) epilogue(std::true_type{});
+            else epilogue(std::false_type{});
             if (tid == 0) tickets[parity] = next_ticket;
             if (!(ablate & 16)) __builtin_amdgcn_s_setprio(0);
 #ifdef LDX_TUNING
@@ -602,7 +661,7 @@ static int launch_mfma(const void *alt, const double *fa, const double *fr, cons
                        uint32_t *out_n11, hipStream_t s)
 {
     const uint32_t nch = n_chunks(n_hap);
-    const size_t lds = 2u * kBBuf + (kSlab + kMfmaWaves * kRows64) * 4u * sizeof(double) + 16u;
+    const size_t lds = 2u * kBBuf + (kSlab + kMfmaWaves * kRows64) * 4u * sizeof(double) + 32u;
     int dev = 0, cus = 256;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&

@@ -41,3 +41,14 @@ for idx in range(int(st[:, 3].max())):
     s4 = sel[:, 6 + 4 * idx: 10 + 4 * idx].astype(np.int64)
     print(f"  pass #{idx}: n={len(sel):5d} start(p50, rel)={np.median(s4[:, 0] - tmin):9.0f}  K={np.median(s4[:, 2] - s4[:, 1]):7.0f}  E={np.median(s4[:, 3] - s4[:, 2]):7.0f}  end(p50)={np.median(s4[:, 3] - tmin):9.0f} end(max)={(s4[:, 3] - tmin).max():9.0f}")
     if idx >= 5: break
+
+# in-chunk stamps (builds with -DLDX_CHUNK_STAMPS): six s_memtime points of one chunk of each wave's second pass
+cs = st[:, 6 + 4 * (passes - 2): 6 + 4 * (passes - 2) + 6].astype(np.int64)
+cs = cs[(cs[:, 0] > 0) & (cs[:, 5] > cs[:, 0])]
+if len(cs) and st[:, 3].max() < passes - 2:
+    d = np.diff(cs, axis=1)
+    names = ["loads+step0", "step1", "step2", "barrier wait", "step3"]
+    print("in-chunk segments (cycles, median / p95) over", len(cs), "waves:")
+    for k, nm in enumerate(names):
+        print(f"   {nm:14s} {np.median(d[:, k]):7.0f} {np.percentile(d[:, k], 95):7.0f}")
+    print(f"   {'chunk total':14s} {np.median(cs[:, 5] - cs[:, 0]):7.0f}")
