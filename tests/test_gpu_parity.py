@@ -158,6 +158,48 @@ def test_epilogue_small_n_exhaustive(gpu, small_n):
         assert np.max(np.abs(raw[:, 0] - o[0]), initial=0) <= 1e-6
 
 
+@pytest.mark.parametrize("n", [5008, 1008, 2504])
+def test_epilogue_random_tuples_at_panel_sizes(gpu, n):
+    """Two million count tuples at the real haplotype counts against the C restatement (itself pinned to the
+    reference's outputs): common and rare alleles, singletons, monomorphic variants, missing codes (a + r < n), pairs
+    at |Dn| <= 2 where the reference's cancellation error is largest, and exact-tie candidates.  ld_from_counts
+    runs every production epilogue variant on each tuple and poisons the result if they disagree."""
+    from ld_tools_amd import ld_from_counts
+    from oracle import c_oracle
+
+    rng = np.random.RandomState(n)
+    m = 2_000_000
+    kind = rng.randint(0, 6, m)
+    u = rng.rand(m)
+    a1 = np.where(kind == 1, rng.randint(0, 4, m), (np.sin(np.pi / 2 * u) ** 2 * n).astype(np.int64))
+    a2 = np.where(kind == 2, rng.randint(0, 4, m), (np.sin(np.pi / 2 * rng.rand(m)) ** 2 * n).astype(np.int64))
+    miss1 = np.where(kind == 3, rng.randint(0, n // 3, m), 0)
+    miss2 = np.where(kind == 3, rng.randint(0, n // 3, m), 0)
+    a1 = np.minimum(a1, n - miss1)
+    a2 = np.minimum(a2, n - miss2)
+    r1, r2 = n - miss1 - a1, n - miss2 - a2
+    lo = np.maximum(0, a1 + a2 - n)                      # feasible n11 range (ignoring missing: widened below)
+    hi = np.minimum(a1, a2)
+    indep = np.rint(a1.astype(np.float64) * a2 / n).astype(np.int64)
+    n11 = np.where(kind == 4, indep + rng.randint(-2, 3, m), lo + (rng.rand(m) * (hi - lo + 1)).astype(np.int64))
+    n11 = np.where(kind == 5, rng.choice([0, 1], m) * hi + (1 - rng.choice([0, 1], m)) * lo, n11)
+    n11 = np.clip(n11, np.where(kind == 3, 0, lo), hi)
+    arrs = [x.astype(np.uint32) for x in (n11, a1, r1, a2, r2)]
+    raw, rnd, flags = ld_from_counts(n, *arrs)
+    rnd, flags = rnd.cpu().numpy(), flags.cpu().numpy()
+    o_rsq_raw, o_dp_raw, o_rsq, o_dp, o_flags = c_oracle.ld_from_counts_v(n, *arrs, libm_pow=True)
+    assert not np.isnan(rnd).any()                                            # the epilogue variants agree
+    assert np.array_equal(flags, o_flags)
+    assert np.array_equal(flags_of(rnd), o_flags)
+    small = (o_rsq < 1000.0) & (o_dp < 1000.0)       # float32(k / 1e4) identifies k while ulp < 1e-4, i.e. below 1024
+    assert small.mean() > 0.99
+    assert np.array_equal(k_of(rnd[small, 0]), np.rint(o_rsq[small] * 1e4).astype(np.int64))
+    assert np.array_equal(k_of(rnd[small, 1]), np.rint(o_dp[small] * 1e4).astype(np.int64))
+    raw = raw.cpu().numpy()
+    assert np.array_equal(raw[:, 1], o_dp_raw)                                # unrounded D': bit-identical
+    assert np.max(np.abs(raw[:, 0] - o_rsq_raw) / np.maximum(1.0, np.abs(o_rsq_raw))) <= 1e-6
+
+
 def test_epilogue_kat(gpu, kat):
     from ld_tools_amd import ld_from_counts
 
@@ -166,7 +208,7 @@ def test_epilogue_kat(gpu, kat):
         raw, rnd, flags = ld_from_counts(n, [n11], [a1], [r1], [a2], [r2])
         e = item["expect"]
         f = int(flags[0])
-        # the float32 cell holds k = value * 10^4 exactly up to k < 2^24 (values below 1677.7); the D' >> 1
+        # the float32 cell identifies k = value * 10^4 while its ulp is below 1e-4 (values below 1024); the D' >> 1
         # tuples (a + r < n with a vanishing bound) are checked through the unrounded fp64 output instead
         pick = lambda col, w: round(float(rnd[0, col]), 4) if w < 1000 else round(float(raw[0, col]), 4)  # noqa: E731
         got_r = 0 if f & 2 else pick(0, e["r_square"])
