@@ -149,7 +149,7 @@ def main():
     def step(k=None):
         nonlocal out, panel
         if use_dist:
-            panel = ldist.all_gather_panel(local, n_snps, n_hap)      # the exchange step (RCCL all-gather)
+            panel = ldist.all_gather_panel(local, n_snps, n_hap, out=panel)   # the exchange step: ONE RCCL all-gather
         if k is not None:
             ev0[k].record()
         out = ld_triangle(panel, unit_range=(u0, u1), out=out)

@@ -99,14 +99,70 @@ def gather_shards(dst, src, sizes, group=None):
         off += n
 
 
-def all_gather_panel(local, n_snps: int, n_hap: int, group=None):
+def fused_gather(full, local, slabs, slab_bytes: int, group=None, stage=None):
+    """ONE all-gather for a whole panel shard.  ``full`` / ``local`` are dicts of 1-D tensors (any device /
+    backend): 'alt' (uint8, whole slab images), 'acnt', 'rcnt' (int32, 128 per slab) and optionally 'ref'; ``local``
+    holds this rank's slabs (or is None), ``full`` receives all ranks' in rank order; ``slabs[r]`` = slabs of rank r.
+
+    Every rank contributes a single byte shard [ALT: big slabs | acnt | rcnt (| REF: big slabs)], big = the largest
+    rank's slab count; the pieces are then copied to their places (strided copies when the shards are equal).
+    Returns the (send, recv) staging buffers for re-use.
+    """
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    with_ref = "ref" in full
+    big = max(slabs)
+    cnt_bytes = SLAB * 4
+    per_slab = slab_bytes * (2 if with_ref else 1) + 2 * cnt_bytes
+    dev = full["alt"].device
+    if stage is None or stage[0].numel() != big * per_slab or stage[1].numel() != world * big * per_slab:
+        stage = (torch.zeros(big * per_slab, dtype=torch.uint8, device=dev),
+                 torch.empty(world * big * per_slab, dtype=torch.uint8, device=dev))
+    send, recv = stage
+    mine = slabs[rank]
+    o_acnt = big * slab_bytes
+    o_rcnt = o_acnt + big * cnt_bytes
+    o_ref = o_rcnt + big * cnt_bytes
+    if local is not None and mine:
+        send[: mine * slab_bytes] = local["alt"][: mine * slab_bytes]
+        send[o_acnt: o_acnt + mine * cnt_bytes] = local["acnt"][: mine * SLAB].view(torch.uint8)
+        send[o_rcnt: o_rcnt + mine * cnt_bytes] = local["rcnt"][: mine * SLAB].view(torch.uint8)
+        if with_ref:
+            send[o_ref: o_ref + mine * slab_bytes] = local["ref"][: mine * slab_bytes]
+    dist.all_gather_into_tensor(recv, send, group=group)
+    shard = recv.view(world, big * per_slab)
+    acnt8, rcnt8 = full["acnt"].view(torch.uint8), full["rcnt"].view(torch.uint8)
+    if len(set(slabs)) == 1:                       # equal shards: one strided copy per piece
+        full["alt"].view(world, big * slab_bytes).copy_(shard[:, :o_acnt])
+        acnt8.view(world, big * cnt_bytes).copy_(shard[:, o_acnt:o_rcnt])
+        rcnt8.view(world, big * cnt_bytes).copy_(shard[:, o_rcnt:o_ref])
+        if with_ref:
+            full["ref"].view(world, big * slab_bytes).copy_(shard[:, o_ref:])
+    else:
+        off = 0
+        for r, n in enumerate(slabs):
+            full["alt"][off * slab_bytes: (off + n) * slab_bytes] = shard[r, : n * slab_bytes]
+            acnt8[off * cnt_bytes: (off + n) * cnt_bytes] = shard[r, o_acnt: o_acnt + n * cnt_bytes]
+            rcnt8[off * cnt_bytes: (off + n) * cnt_bytes] = shard[r, o_rcnt: o_rcnt + n * cnt_bytes]
+            if with_ref:
+                full["ref"][off * slab_bytes: (off + n) * slab_bytes] = shard[r, o_ref: o_ref + n * slab_bytes]
+            off += n
+    return stage
+
+
+def all_gather_panel(local, n_snps: int, n_hap: int, group=None, out=None, with_ref: bool = False):
     """All-gather per-rank slab shards into a full PackedPanel (device tensors, RCCL).
 
     ``local`` is the PackedPanel of this rank's rows (slab_partition(n_snps, world)[rank]), or None
     when the rank owns no rows; its planes are whole slab images, so concatenating the ranks' planes
-    in rank order yields the tiled plane of the full panel.
+    in rank order yields the tiled plane of the full panel.  One collective per call (fused_gather): a ring
+    all-gather over xGMI is latency-bound at these sizes (8 MB per rank at 100k x 5008 over 8 GPUs), so one
+    call instead of four is what matters.  The REF plane only feeds the per-SNP counts, which travel anyway,
+    so it is gathered only on request.  ``out`` re-uses a full panel (and its staging buffers).
     """
-    import torch
     import torch.distributed as dist
 
     from .panel import PackedPanel, require_gpu
@@ -114,18 +170,15 @@ def all_gather_panel(local, n_snps: int, n_hap: int, group=None):
     world = dist.get_world_size(group)
     parts = slab_partition(n_snps, world)
     dev = local.device if local is not None else require_gpu()
-    full = PackedPanel.empty(n_snps, n_hap, dev)
+    full = out if out is not None else PackedPanel.empty(n_snps, n_hap, dev)
     slab_bytes = ((n_hap + 127) // 128) * SLAB * 16
     slabs = [(e - b + SLAB - 1) // SLAB for (b, e) in parts]
-
-    def gather(dst, src, per_slab):
-        if src is None:
-            src = torch.empty(0, dtype=dst.dtype, device=dev)
-        gather_shards(dst, src, [n * per_slab for n in slabs], group)
-
-    gather(full.alt, None if local is None else local.alt, slab_bytes)
-    gather(full.ref, None if local is None else local.ref, slab_bytes)
-    gather(full.acnt, None if local is None else local.acnt, SLAB)
-    gather(full.rcnt, None if local is None else local.rcnt, SLAB)
+    fd = {"alt": full.alt, "acnt": full.acnt, "rcnt": full.rcnt}
+    ld = None if local is None else {"alt": local.alt, "acnt": local.acnt, "rcnt": local.rcnt}
+    if with_ref:
+        fd["ref"] = full.ref
+        if ld is not None:
+            ld["ref"] = local.ref
+    full._gather_stage = fused_gather(fd, ld, slabs, slab_bytes, group, getattr(full, "_gather_stage", None))
     full.refresh_stats()
     return full

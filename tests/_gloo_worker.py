@@ -35,7 +35,7 @@ def tiled_plane(codes: np.ndarray, n_hap: int) -> np.ndarray:
 def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    for n_snps, n_hap in [(512, 200), (700, 137)]:       # equal and uneven slab shards
+    for n_snps, n_hap in [(512, 200), (700, 137), (600, 70)]:       # equal slab shards, ragged last slab, uneven slab counts
         full_codes = synth.synth_codes_host(n_snps, n_hap, seed=3, miss=0.01)
         parts = ldist.slab_partition(n_snps, world)
         b, e = parts[rank]
@@ -48,6 +48,34 @@ def main():
         ldist.gather_shards(dst, shard, sizes)
         want = tiled_plane(full_codes, n_hap)
         assert np.array_equal(dst.numpy(), want), "gathered plane differs from the whole-panel plane"
+
+        # the one-collective exchange of bench.py / all_gather_panel (fused_gather), with and without the REF plane,
+        # twice through the same staging buffers
+        slabs = [(pe - pb + 127) // 128 for (pb, pe) in parts]
+        npad_local, npad_full = slabs[rank] * 128, sum(slabs) * 128
+        acnt = np.zeros(npad_local, dtype=np.int32)
+        rcnt = np.zeros(npad_local, dtype=np.int32)
+        acnt[: e - b] = (mine == 1).sum(axis=1)
+        rcnt[: e - b] = (mine == 0).sum(axis=1)
+        ref_shard = torch.from_numpy(tiled_plane((mine == 0).astype(np.int8), n_hap))
+        for with_ref in (False, True):
+            local = {"alt": shard, "acnt": torch.from_numpy(acnt), "rcnt": torch.from_numpy(rcnt)}
+            full = {"alt": torch.zeros(sum(sizes), dtype=torch.uint8), "acnt": torch.zeros(npad_full, dtype=torch.int32),
+                    "rcnt": torch.zeros(npad_full, dtype=torch.int32)}
+            if with_ref:
+                local["ref"] = ref_shard
+                full["ref"] = torch.zeros(sum(sizes), dtype=torch.uint8)
+            stage = None
+            for _ in range(2):
+                stage = ldist.fused_gather(full, local, slabs, slab_bytes, stage=stage)
+            assert np.array_equal(full["alt"].numpy(), want), "fused gather: ALT plane"
+            fa = np.zeros(npad_full, dtype=np.int32)
+            fr_ = np.zeros(npad_full, dtype=np.int32)
+            fa[:n_snps] = (full_codes == 1).sum(axis=1)
+            fr_[:n_snps] = (full_codes == 0).sum(axis=1)
+            assert np.array_equal(full["acnt"].numpy(), fa) and np.array_equal(full["rcnt"].numpy(), fr_), "fused gather: counts"
+            if with_ref:
+                assert np.array_equal(full["ref"].numpy(), tiled_plane((full_codes == 0).astype(np.int8), n_hap))
 
         # sharded triangle: this rank's unit range, cells through the oracle
         u0, u1 = ldist.unit_partition(n_snps, world)[rank]

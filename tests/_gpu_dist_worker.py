@@ -1,0 +1,55 @@
+"""Worker for tests/test_gpu_dist.py: world_size-2 rehearsal of the sharded ld_triangle on ONE card.
+
+Both ranks use cuda:0 and the gloo backend (RCCL needs one device per rank; the exchange code path is the same
+collective call).  Each rank packs only its slab shard, the shards are exchanged with all_gather_panel (one fused
+all-gather), every rank runs ld_triangle on its unit range of the gathered panel, and compares planes, counts and
+its shard of the triangle with the panel packed from all rows in this process.
+"""
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+from ld_tools_amd import PackedPanel, ld_triangle, synth  # noqa: E402
+from ld_tools_amd import dist as ldist  # noqa: E402
+from ld_tools_amd._lib import UNIT_PAIRS  # noqa: E402
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    for n_snps, n_hap in [(1024, 5008), (1500, 1008), (700, 333)]:      # equal shards, uneven slab counts, ragged last slab
+        b, e = ldist.slab_partition(n_snps, world)[rank]
+        mine = synth.synth_codes_device(e - b, n_hap, seed=5, miss=0.002, snp_offset=b, device=dev)
+        local = PackedPanel.from_codes(mine)
+        panel = None
+        for _ in range(2):                                              # second call re-uses panel and staging buffers
+            panel = ldist.all_gather_panel(local, n_snps, n_hap, out=panel)
+        whole = PackedPanel.from_codes(synth.synth_codes_device(n_snps, n_hap, seed=5, miss=0.002, device=dev))
+        assert torch.equal(panel.alt, whole.alt), "gathered ALT plane"
+        assert torch.equal(panel.acnt, whole.acnt) and torch.equal(panel.rcnt, whole.rcnt), "gathered counts"
+        assert torch.equal(panel.fa, whole.fa) and torch.equal(panel.q, whole.q), "frequency vectors"
+        u0, u1 = ldist.unit_partition(n_snps, world)[rank]
+        part = ld_triangle(panel, unit_range=(u0, u1), want_n11=True)
+        full = ld_triangle(whole, want_n11=True)
+        assert torch.equal(part.ld32.view(torch.int32), full.ld32[u0 * UNIT_PAIRS: u1 * UNIT_PAIRS].view(torch.int32)), "shard results"
+        assert torch.equal(part.n11, full.n11[u0 * UNIT_PAIRS: u1 * UNIT_PAIRS]), "shard counts"
+        with_ref = ldist.all_gather_panel(local, n_snps, n_hap, with_ref=True)
+        assert torch.equal(with_ref.ref, whole.ref), "gathered REF plane"
+    torch.cuda.synchronize()
+    dist.barrier()
+    if rank == 0:
+        print("GPU_DIST_OK")
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
