@@ -25,8 +25,9 @@
 //     the popcount kernel and the oracle.
 #include <stdlib.h>
 
-#include <atomic>
+#include <mutex>
 #include <type_traits>
+#include <unordered_map>
 
 #include "ldx_common.h"
 #include "ldx_tile.h"
@@ -149,8 +150,8 @@ __host__ __device__ inline uint32_t mfma_pass_base(uint32_t t, uint32_t n_slabs)
     return c(n_slabs) - c(n_slabs - t);
 }
 
-// ticket counters of the dynamic pass scheduler: {next ticket, workgroups finished}; self-resetting, one pair
-// per launch in flight (round-robin over a pool, so launches on different streams do not share a pair)
+// ticket counters of the dynamic pass scheduler: {next ticket, workgroups finished}; one pair per stream (host side:
+// launch_mfma), zeroed before every launch and re-armed by the last workgroup out
 constexpr uint32_t kSchedSlots = 256;
 __device__ uint32_t g_sched[kSchedSlots][2];
 
@@ -686,14 +687,29 @@ static int launch_mfma(const void *alt, const double *fa, const double *fr, cons
     uint64_t grid = (uint64_t)cus * (8u / kMfmaWaves);   // persistent: 8 waves per CU = two workgroups
     if (grid > p_end - p_begin) grid = p_end - p_begin;
     if (grid < 1) grid = 1;
+    // One counter pair per STREAM (launches of one stream are ordered, so they may share it; launches of different
+    // streams may overlap, so they must not), zeroed on the stream before every launch: a kernel that was killed
+    // mid-flight cannot leave stale tickets behind.  The kernel's own re-arming stays as a second line.
     static uint32_t (*sched_pool)[2] = nullptr;
-    static std::atomic<uint32_t> sched_next{0};
-    if (!sched_pool) {
-        void *sym = nullptr;
-        LDX_HIP(hipGetSymbolAddress(&sym, HIP_SYMBOL(g_sched)));
-        sched_pool = reinterpret_cast<uint32_t (*)[2]>(sym);
+    static std::mutex sched_mutex;
+    static std::unordered_map<hipStream_t, uint32_t> sched_slot;
+    uint32_t slot;
+    {
+        std::lock_guard<std::mutex> lock(sched_mutex);
+        if (!sched_pool) {
+            void *sym = nullptr;
+            LDX_HIP(hipGetSymbolAddress(&sym, HIP_SYMBOL(g_sched)));
+            sched_pool = reinterpret_cast<uint32_t (*)[2]>(sym);
+        }
+        auto it = sched_slot.find(s);
+        if (it == sched_slot.end()) {
+            LDX_REQUIRE(sched_slot.size() < kSchedSlots, "more than 256 streams have launched ld_triangle in this process");
+            it = sched_slot.emplace(s, (uint32_t)sched_slot.size()).first;
+        }
+        slot = it->second;
     }
-    uint32_t *sched = sched_pool[sched_next.fetch_add(1) % kSchedSlots];
+    uint32_t *sched = sched_pool[slot];
+    LDX_HIP(hipMemsetAsync(sched, 0, 2 * sizeof(uint32_t), s));
     int ablate = 0;
     unsigned long long *stamps = nullptr;
 #ifdef LDX_TUNING
