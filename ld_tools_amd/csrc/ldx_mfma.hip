@@ -1,28 +1,33 @@
-// ld_triangle on the matrix cores: n11 = G . G^T with {0,1} int8 operands (v_mfma_i32_32x32x32_i8),
-// fused with the same fp64 epilogue as the popcount kernel.  calc_ld.py:32 for 8192 pairs per wave unit.
+// ld_triangle on the matrix cores: n11 = G . G^T with int8 operands (v_mfma_i32_32x32x32_i8), fused with the
+// count-domain fp64 epilogue (ldx_common.h).  calc_ld.py:30-97 for 8192 pairs per wave unit.
 //
 // Why: AND + BCNT run at 64 lanes/clk/CU (no packed form), i.e. 16 haplotype-pairs per lane-instruction;
 // the int8 MFMA does 1024 MACs/clk/SIMD -- 4x the VALU ceiling -- so the count moves to the matrix pipe
 // and the VALU is left with expanding bits to bytes and with the epilogue.
 //
 // Structure
-//   * 256-thread workgroups (4 waves), two per CU (<= 256 VGPRs, 36 KiB LDS each): one wave per SIMD and
-//     workgroup, so the partner on a SIMD belongs to the OTHER workgroup and drifts out of phase -- one
-//     runs its VALU epilogue while the other feeds the matrix pipe.
-//   * a wave's unit is 64 i-rows x 128 j-rows: 2 x 4 accumulator tiles of 32x32 (128 VGPRs); the four
-//     waves of a workgroup take four consecutive units of the same j-tile.
+//   * 256-thread workgroups (4 waves), two per CU (<= 256 VGPRs, ~48 KiB LDS each): one wave per SIMD and
+//     workgroup, so the partner on a SIMD belongs to the OTHER workgroup -- one runs its VALU epilogue while
+//     the other feeds the matrix pipe.
+//   * a wave's unit is 64 i-rows x 128 j-rows: 2 x 4 accumulator tiles of 32x32 (128 VGPRs); a PASS is four
+//     consecutive units of one j-tile, one per wave; passes are handed out by a ticket counter in global
+//     memory (dynamic: workgroups do not run at the same speed).
 //   * B side (the 128 j-rows, shared by the 4 waves): per 128-haplotype chunk the workgroup expands the
-//     j-tile's bits to bytes ONCE (each lane: 64 bits -> 4 x ds_write_b128) into a double-buffered LDS
-//     image [128 rows][144 B] (rows padded by 16 B: a 16-lane group of ds_read_b128 then hits 16 distinct
-//     16-byte slots); one barrier per chunk.  Fragments are plain ds_read_b128.
+//     j-tile's bits to bytes ONCE (each lane: 64 bits -> 4 x ds_write_b128, one per K-step) into a
+//     double-buffered LDS image [128 rows][144 B] (rows padded by 16 B: a 16-lane group of ds_read_b128 then
+//     hits 16 distinct 16-byte slots); one LDS-only barrier per chunk.  Fragments are plain ds_read_b128.
 //   * A side (a wave's own 64 rows): each lane loads the 16-byte chunk of "its" row (row = lane % 32 of
-//     each 32-row tile; 32 consecutive rows of a chunk are 512 contiguous bytes), three chunks deep in
-//     registers, and expands 16 bits per K-step in registers (bfe, * 0x00204081, & 0x01010101).
-//   * A and B are expanded from the same bit positions by the same arithmetic, so whatever order the
-//     hardware gives the 16 k-slots of a lane, slot s of A meets slot s of B: the sum over k is the
-//     AND-popcount.  Row/column placement follows the documented 32x32 C/D map
+//     each 32-row tile; 32 consecutive rows of a chunk are 512 contiguous bytes) three chunks ahead with
+//     hand-issued global loads (hand-counted s_waitcnt vmcnt), and expands 16 bits per K-step in registers.
+//   * Operand values: hap bit i of a nibble becomes the byte 1 << i on the A side (v_perm_b32 byte replicate
+//     + AND) and 8 >> i on the B side (multiply-spread), slot for slot, so every co-occurrence adds 8: the
+//     accumulators hold 8 * n11.  Row/column placement follows the documented 32x32 C/D map
 //     (col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)); tests compare every cell with
 //     the popcount kernel and the oracle.
+//   * Epilogue: per-SNP operands (counts and reciprocals) staged in LDS per pass / per tile; two pairs at a
+//     time through ld_multi_fast2; a "clean" variant for interior units of ordinary SNPs; pairs that are not
+//     provably rounded like the reference go through the op-for-op mirror.
+// DESIGN.md section 3.1 has the measurements behind each of these choices.
 #include <stdlib.h>
 
 #include <mutex>
