@@ -165,6 +165,10 @@ int ldx_area_dev(const void *alt, const double *fa, const double *fr, const doub
                  double thres, ldx_hit *hits, uint64_t hit_cap, uint64_t *n_hits, void *workspace,
                  size_t workspace_bytes, void *stream);
 size_t ldx_area_workspace_bytes(uint32_t n_snps, uint32_t n_hap, uint32_t n_query);
+/* kernel behind ldx_area_dev: LDX_PATH_AUTO (matrix-pipe band when >= 1/4 of the SNPs are queries, popcount scan
+ * otherwise), LDX_PATH_POPCOUNT, LDX_PATH_MFMA; the hit sets are identical */
+int ldx_set_area_path(int path);
+int ldx_get_area_path(void);
 
 /* ---- synthetic panels: deterministic, identical on host and device ------ */
 /* codes int8 [n_snps][ld_codes] receive global SNPs [snp_offset, snp_offset + n_snps) (a rank's

@@ -225,10 +225,24 @@ area_scan_kernel(const uint4 *__restrict__ alt, const uint4 *__restrict__ qalt, 
 
 using namespace ldx;
 
+// which kernel runs ld_area: LDX_PATH_AUTO = the matrix-pipe band when at least a quarter of the SNPs are queries
+// (it evaluates every pair of the band once for both orders), the popcount scan of query rows otherwise
+static int g_area_path = LDX_PATH_AUTO;
+
+extern "C" int ldx_set_area_path(int path)
+{
+    LDX_REQUIRE(path == LDX_PATH_AUTO || path == LDX_PATH_POPCOUNT || path == LDX_PATH_MFMA, "unknown path");
+    g_area_path = path;
+    return LDX_OK;
+}
+
+extern "C" int ldx_get_area_path(void) { return g_area_path; }
+
 extern "C" size_t ldx_area_workspace_bytes(uint32_t n_snps, uint32_t n_hap, uint32_t n_query)
 {
     AreaWs w;
-    return carve(w, nullptr, n_snps, n_hap, n_query ? n_query : 1);
+    const size_t a = carve(w, nullptr, n_snps, n_hap, n_query ? n_query : 1), b = area_mfma_workspace_bytes(n_snps);
+    return a > b ? a : b;
 }
 
 extern "C" int ldx_area_dev(const void *alt, const double *fa, const double *fr, const double *q, uint32_t n_snps,
@@ -247,8 +261,12 @@ extern "C" int ldx_area_dev(const void *alt, const double *fa, const double *fr,
     }
     AreaWs w;
     const size_t need = carve(w, workspace, n_snps, n_hap, n_query);
-    LDX_REQUIRE(workspace_bytes >= need, "workspace too small (see ldx_area_workspace_bytes)");
+    LDX_REQUIRE(workspace_bytes >= need && workspace_bytes >= area_mfma_workspace_bytes(n_snps),
+                "workspace too small (see ldx_area_workspace_bytes)");
     hipStream_t s = (hipStream_t)stream;
+    if (g_area_path == LDX_PATH_MFMA || (g_area_path == LDX_PATH_AUTO && (uint64_t)n_query * 4u >= n_snps && n_snps >= 2))
+        return area_mfma(alt, fa, fr, q, n_snps, n_hap, positions, queries, n_query, flank, measure, thres, hits, hit_cap,
+                         n_hits, workspace, s);
     const uint32_t qpad = ldx_padded_snps(n_query), T = ldx::n_slabs(n_snps), nch = ldx::n_chunks(n_hap);
     LDX_HIP(hipMemsetAsync(n_hits, 0, sizeof(uint64_t), s));
     area_gather_kernel<<<(qpad + 3u) / 4u, 256, 0, s>>>((const uint4 *)alt, fa, fr, q, positions, queries, n_query, qpad,

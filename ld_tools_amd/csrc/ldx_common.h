@@ -24,6 +24,13 @@ int triangle_mfma(const void *alt, const double *fa, const double *fr, const dou
                   uint64_t unit_begin, uint64_t unit_end, ldx_ld32 *out, ldx_ld64 *out_raw, uint32_t *out_n11,
                   hipStream_t s);
 
+// ld_area on the matrix pipe (ldx_mfma.hip): all (query, opposing) pairs inside the +-flank band through the MFMA
+// kernel; same hit contract as the popcount scan of ldx_area.hip
+size_t area_mfma_workspace_bytes(uint32_t n_snps);
+int area_mfma(const void *alt, const double *fa, const double *fr, const double *q, uint32_t n_snps, uint32_t n_hap,
+              const int64_t *positions, const uint32_t *queries, uint32_t n_query, int64_t flank, int measure, double thres,
+              ldx_hit *hits, uint64_t hit_cap, uint64_t *n_hits, void *workspace, hipStream_t s);
+
 #define LDX_HIP(call)                                                                       \
     do {                                                                                    \
         hipError_t e_ = (call);                                                             \

@@ -66,6 +66,7 @@ constexpr int kMfmaThreads = kMfmaWaves * 64;
 constexpr uint32_t kRows64 = 64;              // i-rows per wave unit
 constexpr uint32_t kBRow = 144;               // bytes per expanded j-row in LDS (128 + 16 pad)
 constexpr uint32_t kBBuf = kSlab * kBRow;     // one buffer: 18 KiB
+constexpr uint32_t kStat = 6;                  // doubles per SNP in the LDS operand tables (16-byte aligned rows)
 [[maybe_unused]] constexpr uint32_t kStampPasses = 40, kStampStride = 6 + 4 * kStampPasses;   // tuning builds: LDX_STAMP
 
 // Bits to int8 operands.  The matrix pipe only needs A[k] * B[k] to be the SAME constant for every haplotype k
@@ -167,14 +168,31 @@ __device__ uint32_t g_sched[kSchedSlots][2];
 constexpr uint32_t kCuTokens = 4096;
 __device__ uint32_t g_cu_token[kCuTokens];
 
-template <bool kRaw, bool kN11>
+// Arguments of the banded (ld_area) use of the kernel: the same passes, K loop and operand staging; the pass list is
+// cut to the units a window of +-flank can reach, and the epilogue turns every pair into up to two thresholded
+// hits, (query = row, opposing = column) and (query = column, opposing = row)  (ld_area.py:152-276).
+struct AreaArgs {
+    const int64_t *pos;            // [n_snps] ascending 1-based positions
+    const uint8_t *is_query;       // [n_snps] 1 = the SNP is a query
+    const uint32_t *pass_base;     // [T + 1] prefix sum of passes per j-tile (pass_base[T] = all passes)
+    const uint32_t *g_end;         // [T] one past the last 64-row group a column of tile t can pair with
+    ldx_hit *hits;
+    unsigned long long *n_hits;
+    uint64_t hit_cap;
+    double flank, k_thres;
+    int measure;
+};
+constexpr uint32_t kHitBatch = 256;   // hit slots a wave reserves per atomic (as in ldx_area.hip)
+
+template <bool kRaw, bool kN11, bool kArea = false>
 __global__ void __launch_bounds__(kMfmaThreads, 2)
 triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ fa, const double *__restrict__ fr,
                      const double *__restrict__ q, uint32_t n_snps, uint32_t n_slabs, uint32_t nchunks, double n,
                      double rn, uint64_t u_begin, uint64_t u_end, ldx_ld32 *__restrict__ out, ldx_ld64 *__restrict__ raw,
-                     uint32_t *__restrict__ n11, uint32_t p_begin, uint32_t p_end, uint32_t *sched, int ablate_arg,
-                     unsigned long long *stamps)
+                     uint32_t *__restrict__ n11, uint32_t p_begin, uint32_t p_end_arg, uint32_t *sched, int ablate_arg,
+                     unsigned long long *stamps, AreaArgs aa)
 {
+    const uint32_t p_end = kArea ? aa.pass_base[n_slabs] : p_end_arg;   // area: the plan kernel's total
     // `ablate` (tuning builds only, -DLDX_TUNING + env LDX_ABLATE; a compile-time 0 in the product, so that
     // none of its tests survives as a branch): 1 = no epilogue arithmetic, 2 = one chunk instead of all (no
     // counting), 4 = no stores, 8 = no stagger, 64 = first half of the grid K loop only / second half epilogue
@@ -192,7 +210,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
     unsigned char *bexp = reinterpret_cast<unsigned char *>(lds);   // [2][128][144]
     // per-SNP operands of the fast epilogue (ldx_common.h, FastCol / FastRow): the j-tile's 128 columns, written
     // once per tile, and this wave's 64 rows, written once per pass
-    double *cstat = reinterpret_cast<double *>(bexp + 2u * kBBuf);   // [128][4]
+    double *cstat = reinterpret_cast<double *>(bexp + 2u * kBBuf);   // [128][kStat]: FastCol (+ position, is_query for ld_area)
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t l32 = lane & 31u;
@@ -200,7 +218,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
     const uint32_t sel0 = half ? 0x02020202u : 0x00000000u;   // v_perm selectors: this lane's two bytes of an A word
     const uint32_t sel1 = half ? 0x03030303u : 0x01010101u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    double *rstat = cstat + kSlab * 4u + wave * (kRows64 * 4u);       // [64][4], private to the wave
+    double *rstat = cstat + kSlab * kStat + wave * (kRows64 * kStat);   // [64][kStat], private to the wave
     const FastConst fk = fast_const(n, 8.0);
     // In-kernel stamps (tuning builds, env LDX_STAMPS=file): per wave {HW_ID | XCC_ID << 32, realtime, passes}
     // and per pass {start, prologue done, K loop done, epilogue done} in shader cycles; written to a buffer nothing else reads.
@@ -232,7 +250,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
     // do not run at the same speed: two that share a CU and fall into step (K loop beside K loop, epilogue
     // beside epilogue) take ~1.5x as long per pass as two in antiphase, and with an equal static share the
     // slowest pair set the kernel time (max wave lifetime 826k cycles against a median of 533k at 10k SNPs).
-    uint32_t *tickets = reinterpret_cast<uint32_t *>(cstat + kSlab * 4u + kMfmaWaves * (kRows64 * 4u));   // [2]
+    uint32_t *tickets = reinterpret_cast<uint32_t *>(cstat + kSlab * kStat + kMfmaWaves * (kRows64 * kStat));   // [2]
     uint32_t *cols_odd = tickets + 2;   // [2]: per wave of the column stagers, != 0 if one of its columns is not "ordinary"
     auto draw = [&]() { return atomicAdd(&sched[0], 1u); };
     uint32_t parity = 0;
@@ -244,6 +262,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
         token = &g_cu_token[((xcc & 0xFu) << 8) | ((hw >> 8) & 0xFFu)];   // XCC | SE | SH | CU
     }
 
+    uint64_t hit_slot = 0, hit_slot_end = 0;   // area: this wave's unfilled part of its current batch of hit slots
     uint32_t t_prev = 0xFFFFFFFFu;
     for (;;) {   // block-uniform: every wave reaches every barrier
         __syncthreads();   // the ticket is in LDS; every wave is past its previous epilogue (both B buffers free)
@@ -258,20 +277,23 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
             break;
         }
         const uint32_t p = p_begin + ticket;
+        auto pbase = [&](uint32_t tile) { return kArea ? aa.pass_base[tile] : mfma_pass_base(tile, n_slabs); };
         uint32_t t;
         {
             uint32_t lo = 0, hi = n_slabs;   // largest t with pass_base(t) <= p
             while (hi - lo > 1) {
                 const uint32_t mid = (lo + hi) / 2;
-                if (mfma_pass_base(mid, n_slabs) <= p) lo = mid; else hi = mid;
+                if (pbase(mid) <= p) lo = mid; else hi = mid;
             }
             t = lo;
         }
         const bool new_tile = t != t_prev;
         t_prev = t;
         const uint64_t tb = base64(t), te = base64(t + 1u);
-        const uint64_t pass = tb + (uint64_t)(p - mfma_pass_base(t, n_slabs)) * kMfmaWaves;   // its first unit
-        const uint64_t seg_begin = v_begin > tb ? v_begin : tb, seg_end = v_end < te ? v_end : te;
+        const uint64_t pass = tb + (uint64_t)(p - pbase(t)) * kMfmaWaves;   // its first unit
+        // triangle: the units of the tile inside [v_begin, v_end); area: the units the window can reach
+        const uint64_t seg_begin = kArea ? tb : (v_begin > tb ? v_begin : tb);
+        const uint64_t seg_end = kArea ? tb + (aa.g_end[t] > 2u * t ? aa.g_end[t] - 2u * t : 0u) : (v_end < te ? v_end : te);
         // the j-tile's bits for this thread's expansion share: row tid/2, 8 bytes (tid%2) of each chunk
         const uint2 *bsrc = reinterpret_cast<const uint2 *>(alt + (size_t)t * nchunks * kSlab) + tid;
         constexpr uint32_t kBStride = kSlab * 2u;   // uint2 per chunk
@@ -383,17 +405,19 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                     if (lane == 0) cols_odd[wave] = 0u;
                     if (__any(odd) && lane == 0) cols_odd[wave] = 1u;
                     typedef double d2 __attribute__((ext_vector_type(2)));
-                    d2 *dst = reinterpret_cast<d2 *>(cstat + tid * 4u);
+                    d2 *dst = reinterpret_cast<d2 *>(cstat + tid * kStat);
                     dst[0] = d2{c.a, c.ra};
                     dst[1] = d2{c.rr, c.rq};
+                    if (kArea) dst[2] = j < n_snps ? d2{(double)aa.pos[j], (double)aa.is_query[j]} : d2{0.0, 0.0};
                 }
                 const uint32_t i = row0 + lane;
                 const FastRow r = fast_row(fa[i], fr[i], n);
                 rows_ordinary = __all(fast_ordinary(fa[i], fr[i], n));
                 typedef double d2 __attribute__((ext_vector_type(2)));
-                d2 *dst = reinterpret_cast<d2 *>(rstat + lane * 4u);
+                d2 *dst = reinterpret_cast<d2 *>(rstat + lane * kStat);
                 dst[0] = d2{r.a_s, r.ra};
                 dst[1] = d2{r.rr, r.rq_s};
+                if (kArea) dst[2] = i < n_snps ? d2{(double)aa.pos[i], (double)aa.is_query[i]} : d2{0.0, 0.0};
             }
             if (token && tid == 0) {   // the CU's matrix-pipe token (bounded wait; see g_cu_token)
                 uint32_t polls = 0;
@@ -570,18 +594,18 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                     FastRow fr2x[2];
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
-                        const d2 *rs = reinterpret_cast<const d2 *>(rstat + ri[m] * 4u);   // two addresses per wave: broadcast
+                        const d2 *rs = reinterpret_cast<const d2 *>(rstat + ri[m] * kStat);   // two addresses per wave: broadcast
                         const d2 r01 = rs[0], r23 = rs[1];
                         fr2x[m] = FastRow{r01.x, r01.y, r23.x, r23.y};
                     }
-                    const d2 *cs = reinterpret_cast<const d2 *>(cstat + l32 * 4u);
+                    const d2 *cs = reinterpret_cast<const d2 *>(cstat + l32 * kStat);
                     d2 c01n = cs[0], c23n = cs[1];
 #pragma unroll
                     for (int tt = 0; tt < 4; ++tt) {
                         const d2 c01 = c01n, c23 = c23n;
                         if (tt < 3) {   // the next column's operands: their LDS latency hides behind this column's arithmetic
-                            c01n = cs[(tt + 1) * 64];
-                            c23n = cs[(tt + 1) * 64 + 1];
+                            c01n = cs[(tt + 1) * (16 * kStat)];
+                            c23n = cs[(tt + 1) * (16 * kStat) + 1];
                         }
                         const FastCol fcx[2] = {FastCol{c01.x, c01.y, c23.x, c23.y}, FastCol{c01.x, c01.y, c23.x, c23.y}};
                         int a8[2];
@@ -641,6 +665,123 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                     }
             }
             };
+            // ---- ld_area: thresholded hits instead of a dense result ----
+            // Pair (i, j), i > j, pos_i >= pos_j, serves two ordered pairs of the reference's loop:
+            //   A: query i, opposing j -- j lies in i's window iff max(0, pos_i - flank) < pos_j     (ld_area.py:174-177)
+            //   B: query j, opposing i -- iff max(0, pos_j - flank) < pos_i <= pos_j + flank  (the lower bound only bites
+            //      for equal positions with flank 0)
+            // D' and the fast path's r^2 do not depend on the order; the reference's r^2 does in its last bits
+            // ((fa1*fr1)*fa2)*fr2 associates in argument order), so a pair that needs the mirror
+            // gets it once per order.
+            auto area_epilogue = [&]() {
+                uint64_t slot = hit_slot, slot_end = hit_slot_end;
+                const float kthr = (float)aa.k_thres;
+                const bool prefilter = aa.k_thres > 2.0;
+                const double kcand = aa.k_thres - 2.0;
+                auto append = [&](bool keep, uint32_t qrow, uint32_t orow, ldx_ld32 v) {
+                    const unsigned long long mask = __ballot(keep);
+                    if (!mask) return;   // wave-uniform
+                    const uint32_t cnt = __builtin_popcountll(mask);
+                    if (slot + cnt > slot_end) {   // close the old batch (mark what is left invalid), open a new one
+                        for (uint64_t sl = slot + lane; sl < slot_end; sl += 64u)
+                            if (sl < aa.hit_cap) aa.hits[sl].query = 0xFFFFFFFFu;
+                        unsigned long long base = 0;
+                        if (lane == 0) base = atomicAdd(aa.n_hits, (unsigned long long)kHitBatch);
+                        base = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
+                               __builtin_amdgcn_readfirstlane((uint32_t)base);
+                        slot = base;
+                        slot_end = base + kHitBatch;
+                    }
+                    if (keep) {
+                        const uint64_t sl = slot + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+                        if (sl < aa.hit_cap) aa.hits[sl] = ldx_hit{qrow, orow, v.r_square, v.d_prime};
+                    }
+                    slot += cnt;
+                };
+#pragma unroll 1
+                for (int e = 0; e < 16; ++e) {
+                    uint32_t ri[2];
+                    FastRow frx[2];
+                    double pi[2], qi[2];
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        ri[m] = 32u * m + (e & 3) + 8u * (e >> 2) + 4u * half;
+                        const d2 *rs = reinterpret_cast<const d2 *>(rstat + ri[m] * kStat);
+                        const d2 r01 = rs[0], r23 = rs[1], r45 = rs[2];
+                        frx[m] = FastRow{r01.x, r01.y, r23.x, r23.y};
+                        pi[m] = r45.x;
+                        qi[m] = r45.y;
+                    }
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) {
+                        const d2 *cs = reinterpret_cast<const d2 *>(cstat + (32u * tt + l32) * kStat);
+                        const d2 c01 = cs[0], c23 = cs[1], c45 = cs[2];
+                        const FastCol fcx[2] = {FastCol{c01.x, c01.y, c23.x, c23.y}, FastCol{c01.x, c01.y, c23.x, c23.y}};
+                        const double pj = c45.x, qj = c45.y;
+                        const uint32_t j = t * kSlab + 32u * tt + l32;
+                        int a8[2];
+                        ldx_ld32 r2[2];
+                        bool s2[2];
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) a8[m] = acc[m][tt][e];
+                        // Prefilter: hits are rare (r^2 >= 0.8: ~6e-4 of the pairs), so first price the thresholded
+                        // measure alone -- 6 VALU for r^2 * 10^4, 15 for D' * 10^4, exact to ~1e-11 -- and run the full
+                        // epilogue only where some lane comes within 2 units of the threshold (the two orders of a pair
+                        // and the reference's own rounding differ by far less).  A NaN (a count of 0: int-0 results)
+                        // never passes; thresholds <= 2e-4 switch the prefilter off.
+                        if (prefilter) {
+                            bool cand = false;
+#pragma unroll
+                            for (int m = 0; m < 2; ++m) {
+                                const double dn4 = __builtin_fma((double)a8[m], fk.nsc, -(frx[m].a_s * fcx[m].a));
+                                double y;
+                                if (aa.measure == LDX_MEASURE_RSQ) {
+                                    y = (dn4 * (frx[m].rq_s * fcx[m].rq)) * dn4;
+                                } else {
+                                    const bool neg = dn4 < 0.0;
+                                    const double x = neg ? fcx[m].ra : fcx[m].rr, yy = neg ? fcx[m].rr : fcx[m].ra;
+                                    y = __builtin_fabs(dn4) * max_raw(frx[m].ra * x, frx[m].rr * yy);
+                                }
+                                cand = cand || (y >= kcand);
+                            }
+                            if (!__any(cand)) continue;   // wave-uniform: nothing near the threshold in these 128 pairs
+                        }
+                        ld_multi_fast2<2, false>(a8, fk, frx, fcx, r2, s2);
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) {
+                            const uint32_t i = row0 + ri[m];
+                            const bool valid = (i > j) && (i < n_snps);
+                            double low = pi[m] - aa.flank;
+                            low = low < 0.0 ? 0.0 : low;
+                            const bool in_a = valid && qi[m] != 0.0 && low < pj;                 // A: query i, opposing j
+                            double lowj = pj - aa.flank;
+                            lowj = lowj < 0.0 ? 0.0 : lowj;
+                            const bool in_b = valid && qj != 0.0 && lowj < pi[m] && pi[m] <= pj + aa.flank;   // B: query j, opposing i
+                            ldx_ld32 ra = r2[m], rb = r2[m];
+                            if (__builtin_expect(__any(s2[m] && (in_a || in_b)), 0)) {
+                                if (s2[m] && (in_a || in_b)) {
+                                    const double f11 = (double)((uint32_t)a8[m] >> 3) / n;
+                                    ra = ld_pair_mirror(f11, fa[i], fr[i], q[i], fa[j], fr[j]);
+                                    rb = ld_pair_mirror(f11, fa[j], fr[j], q[j], fa[i], fr[i]);
+                                }
+                            }
+                            // rounded value * 10^4 back as an integer (exact for values < 1024; -0.0f = int 0 -> 0)
+                            const float ka = __builtin_rintf((aa.measure == LDX_MEASURE_RSQ ? ra.r_square : ra.d_prime) * 1e4f);
+                            const float kb = __builtin_rintf((aa.measure == LDX_MEASURE_RSQ ? rb.r_square : rb.d_prime) * 1e4f);
+                            append(in_a && ka >= kthr, i, j, ra);                              // ld_area.py:248
+                            append(in_b && kb >= kthr, j, i, rb);
+                        }
+                    }
+                }
+                hit_slot = slot;
+                hit_slot_end = slot_end;
+            };
+            if (kArea) {
+                area_epilogue();
+                if (tid == 0) tickets[parity] = next_ticket;
+                if (!(ablate & 16)) __builtin_amdgcn_s_setprio(0);
+                continue;
+            }
             const bool clean = !kRaw && rows_ordinary && (cols_odd[0] | cols_odd[1]) == 0u &&
                                row0 >= (t + 1u) * kSlab && row0 + kRows64 <= n_snps && (t + 1u) * kSlab <= n_snps &&
                                vv * 8u >= u_begin && vv * 8u + 8u <= u_end;
@@ -659,6 +800,37 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
 #endif
         }
     }
+    if (kArea)   // the unused slots of this wave's last batch
+        for (uint64_t sl = hit_slot + lane; sl < hit_slot_end; sl += 64u)
+            if (sl < aa.hit_cap) aa.hits[sl].query = 0xFFFFFFFFu;
+}
+
+// One ticket-counter pair per STREAM (launches of one stream are ordered, so they may share it; launches of different
+// streams may overlap, so they must not), zeroed on the stream before every launch: a kernel that was killed
+// mid-flight cannot leave stale tickets behind.  The kernel's own re-arming stays as a second line.
+static int acquire_sched(hipStream_t s, uint32_t **sched)
+{
+    static uint32_t (*sched_pool)[2] = nullptr;
+    static std::mutex sched_mutex;
+    static std::unordered_map<hipStream_t, uint32_t> sched_slot;
+    uint32_t slot;
+    {
+        std::lock_guard<std::mutex> lock(sched_mutex);
+        if (!sched_pool) {
+            void *sym = nullptr;
+            LDX_HIP(hipGetSymbolAddress(&sym, HIP_SYMBOL(g_sched)));
+            sched_pool = reinterpret_cast<uint32_t (*)[2]>(sym);
+        }
+        auto it = sched_slot.find(s);
+        if (it == sched_slot.end()) {
+            LDX_REQUIRE(sched_slot.size() < kSchedSlots, "more than 256 streams have launched ld_triangle in this process");
+            it = sched_slot.emplace(s, (uint32_t)sched_slot.size()).first;
+        }
+        slot = it->second;
+    }
+    *sched = sched_pool[slot];
+    LDX_HIP(hipMemsetAsync(*sched, 0, 2 * sizeof(uint32_t), s));
+    return LDX_OK;
 }
 
 template <bool kRaw, bool kN11>
@@ -667,7 +839,7 @@ static int launch_mfma(const void *alt, const double *fa, const double *fr, cons
                        uint32_t *out_n11, hipStream_t s)
 {
     const uint32_t nch = n_chunks(n_hap);
-    const size_t lds = 2u * kBBuf + (kSlab + kMfmaWaves * kRows64) * 4u * sizeof(double) + 32u;
+    const size_t lds = 2u * kBBuf + (kSlab + kMfmaWaves * kRows64) * kStat * sizeof(double) + 32u;
     int dev = 0, cus = 256;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
@@ -692,29 +864,8 @@ static int launch_mfma(const void *alt, const double *fa, const double *fr, cons
     uint64_t grid = (uint64_t)cus * (8u / kMfmaWaves);   // persistent: 8 waves per CU = two workgroups
     if (grid > p_end - p_begin) grid = p_end - p_begin;
     if (grid < 1) grid = 1;
-    // One counter pair per STREAM (launches of one stream are ordered, so they may share it; launches of different
-    // streams may overlap, so they must not), zeroed on the stream before every launch: a kernel that was killed
-    // mid-flight cannot leave stale tickets behind.  The kernel's own re-arming stays as a second line.
-    static uint32_t (*sched_pool)[2] = nullptr;
-    static std::mutex sched_mutex;
-    static std::unordered_map<hipStream_t, uint32_t> sched_slot;
-    uint32_t slot;
-    {
-        std::lock_guard<std::mutex> lock(sched_mutex);
-        if (!sched_pool) {
-            void *sym = nullptr;
-            LDX_HIP(hipGetSymbolAddress(&sym, HIP_SYMBOL(g_sched)));
-            sched_pool = reinterpret_cast<uint32_t (*)[2]>(sym);
-        }
-        auto it = sched_slot.find(s);
-        if (it == sched_slot.end()) {
-            LDX_REQUIRE(sched_slot.size() < kSchedSlots, "more than 256 streams have launched ld_triangle in this process");
-            it = sched_slot.emplace(s, (uint32_t)sched_slot.size()).first;
-        }
-        slot = it->second;
-    }
-    uint32_t *sched = sched_pool[slot];
-    LDX_HIP(hipMemsetAsync(sched, 0, 2 * sizeof(uint32_t), s));
+    uint32_t *sched = nullptr;
+    if (int rc = acquire_sched(s, &sched)) return rc;
     int ablate = 0;
     unsigned long long *stamps = nullptr;
 #ifdef LDX_TUNING
@@ -728,7 +879,7 @@ static int launch_mfma(const void *alt, const double *fa, const double *fr, cons
 #endif
     triangle_mfma_kernel<kRaw, kN11><<<(uint32_t)grid, kMfmaThreads, lds, s>>>(
         (const uint4 *)alt, fa, fr, q, n_snps, n_slabs(n_snps), nch, (double)n_hap, 1.0 / (double)n_hap, unit_begin,
-        unit_end, out, out_raw, out_n11, p_begin, p_end, sched, ablate, stamps);
+        unit_end, out, out_raw, out_n11, p_begin, p_end, sched, ablate, stamps, AreaArgs{});
     LDX_HIP(hipGetLastError());
 #ifdef LDX_TUNING
     if (stamps) {   // tuning only: synchronous; the file holds the stamps of the LAST launch
@@ -759,6 +910,106 @@ int triangle_mfma(const void *alt, const double *fa, const double *fr, const dou
     if (out_n11)
         return launch_mfma<false, true>(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end, out, out_raw, out_n11, s);
     return launch_mfma<false, false>(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end, out, out_raw, out_n11, s);
+}
+
+}  // namespace ldx
+
+// ---- ld_area on the matrix pipe (banded use of the kernel above) --------------------------------------------
+namespace ldx {
+
+__global__ void area_mask_kernel(const uint32_t *__restrict__ queries, uint32_t n_query, uint8_t *__restrict__ is_query)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n_query) is_query[queries[k]] = 1;
+}
+
+// single workgroup: per j-tile the last 64-row group its columns can pair with, then the exclusive scan of the
+// tiles' pass counts
+__global__ void __launch_bounds__(1024) area_band_plan_kernel(const int64_t *__restrict__ pos, uint32_t n_snps, uint32_t T,
+                                                              int64_t flank, uint32_t *__restrict__ g_end,
+                                                              uint32_t *__restrict__ pass_base)
+{
+    __shared__ uint32_t carry;
+    __shared__ uint32_t wsum[16];
+    if (threadIdx.x == 0) { carry = 0; pass_base[0] = 0; }
+    __syncthreads();
+    for (uint32_t t0 = 0; t0 < T; t0 += 1024u) {
+        const uint32_t t = t0 + threadIdx.x;
+        uint32_t cnt = 0;
+        if (t < T) {
+            const uint32_t jlast = ((t + 1u) * kSlab < n_snps ? (t + 1u) * kSlab : n_snps) - 1u;
+            const int64_t lim = pos[jlast] + flank;            // rows with pos <= lim can pair with a column of the tile
+            uint32_t lo = jlast + 1u, hi = n_snps;             // first row index with pos > lim
+            while (lo < hi) { const uint32_t m = (lo + hi) / 2; if (pos[m] > lim) hi = m; else lo = m + 1u; }
+            const uint32_t ge = (lo + kRows64 - 1u) / kRows64;   // lo rows -> groups
+            g_end[t] = ge;
+            const uint32_t units = ge > 2u * t ? ge - 2u * t : 0u;
+            cnt = (units + kMfmaWaves - 1u) / kMfmaWaves;
+        }
+        uint32_t x = cnt;
+        const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(x, off); if (lane >= (uint32_t)off) x += y; }
+        if (lane == 63) wsum[wv] = x;
+        __syncthreads();
+        uint32_t pre = 0;
+        for (uint32_t k = 0; k < wv; ++k) pre += wsum[k];
+        const uint32_t incl = carry + pre + x;
+        if (t < T) pass_base[t + 1u] = incl;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = incl;
+        __syncthreads();
+    }
+}
+
+size_t area_mfma_workspace_bytes(uint32_t n_snps)
+{
+    const size_t T = n_slabs(n_snps);
+    return ((size_t)n_snps + 255u) / 256u * 256u + ((T + 1u) * 4u + 255u) / 256u * 256u + (T * 4u + 255u) / 256u * 256u;
+}
+
+int area_mfma(const void *alt, const double *fa, const double *fr, const double *q, uint32_t n_snps, uint32_t n_hap,
+              const int64_t *positions, const uint32_t *queries, uint32_t n_query, int64_t flank, int measure, double thres,
+              ldx_hit *hits, uint64_t hit_cap, uint64_t *n_hits, void *workspace, hipStream_t s)
+{
+    const uint32_t T = n_slabs(n_snps), nch = n_chunks(n_hap);
+    char *w = (char *)workspace;
+    uint8_t *is_query = (uint8_t *)w;
+    w += ((size_t)n_snps + 255u) / 256u * 256u;
+    uint32_t *pass_base = (uint32_t *)w;
+    w += (((size_t)T + 1u) * 4u + 255u) / 256u * 256u;
+    uint32_t *g_end = (uint32_t *)w;
+    LDX_HIP(hipMemsetAsync(n_hits, 0, sizeof(uint64_t), s));
+    LDX_HIP(hipMemsetAsync(is_query, 0, n_snps, s));
+    area_mask_kernel<<<(n_query + 255u) / 256u, 256, 0, s>>>(queries, n_query, is_query);
+    LDX_HIP(hipGetLastError());
+    area_band_plan_kernel<<<1, 1024, 0, s>>>(positions, n_snps, T, flank, g_end, pass_base);
+    LDX_HIP(hipGetLastError());
+    const size_t lds = 2u * kBBuf + (kSlab + kMfmaWaves * kRows64) * kStat * sizeof(double) + 32u;
+    int dev = 0, cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+        prop.multiProcessorCount > 0)
+        cus = prop.multiProcessorCount;
+    uint32_t *sched = nullptr;
+    if (int rc = acquire_sched(s, &sched)) return rc;
+    AreaArgs aa;
+    aa.pos = positions;
+    aa.is_query = is_query;
+    aa.pass_base = pass_base;
+    aa.g_end = g_end;
+    aa.hits = hits;
+    aa.n_hits = (unsigned long long *)n_hits;
+    aa.hit_cap = hit_cap;
+    aa.flank = (double)flank;
+    aa.k_thres = thres_to_k(thres);
+    aa.measure = measure;
+    const uint64_t units = ldx_triangle_units(n_snps) / 8u;   // 64-row units of the full triangle
+    triangle_mfma_kernel<false, false, true><<<(uint32_t)cus * 2u, kMfmaThreads, lds, s>>>(
+        (const uint4 *)alt, fa, fr, q, n_snps, T, nch, (double)n_hap, 1.0 / (double)n_hap, 0, units * 8u, nullptr, nullptr,
+        nullptr, 0u, 0u, sched, 0, nullptr, aa);
+    LDX_HIP(hipGetLastError());
+    return LDX_OK;
 }
 
 }  // namespace ldx

@@ -34,6 +34,17 @@ def get_triangle_path() -> str:
     return next(k for k, v in PATHS.items() if v == code)
 
 
+def set_area_path(name: str) -> None:
+    """Choose the kernel behind ld_area: 'popcount' (scan of the query rows), 'mfma' (the whole +-flank band on the
+    matrix pipe) or 'auto' (mfma when at least a quarter of the SNPs are queries).  The hit sets are identical."""
+    check(lib.ldx_set_area_path(PATHS[name]), "ldx_set_area_path")
+
+
+def get_area_path() -> str:
+    code = lib.ldx_get_area_path()
+    return next(k for k, v in PATHS.items() if v == code)
+
+
 # --------------------------------------------------------------------------- triangle
 @dataclass
 class TriangleResult:

@@ -44,6 +44,15 @@ def untile(plane_u8: np.ndarray, n_snps: int, n_hap: int) -> np.ndarray:
     return bits[:n_snps, :n_hap].astype(bool), bits
 
 
+@pytest.fixture(params=["popcount", "mfma"])
+def area_path(request, gpu):
+    """Run an ld_area test once per kernel (the popcount scan of query rows and the matrix-pipe band)."""
+    from ld_tools_amd import ops
+    ops.set_area_path(request.param)
+    yield request.param
+    ops.set_area_path("auto")
+
+
 def k_of(x32: np.ndarray) -> np.ndarray:
     return np.rint(x32.astype(np.float64) * 1e4).astype(np.int64)
 
@@ -370,7 +379,7 @@ def test_triangle_bench_size_against_oracle_rows(gpu, path):
 
 
 # ------------------------------------------------------------------ ld_area
-def test_area_matches_golden_drivers(gpu, drivers, panel_codes):
+def test_area_matches_golden_drivers(gpu, area_path, drivers, panel_codes):
     from ld_tools_amd import PackedPanel, ld_area
 
     p = PackedPanel.from_codes(panel_codes[drivers["panel"]])
@@ -394,7 +403,7 @@ def test_area_matches_golden_drivers(gpu, drivers, panel_codes):
                     assert not (g == 0 and np.signbit(g)) and round(float(g), 4) == wv
 
 
-def test_area_banded_against_oracle(gpu):
+def test_area_banded_against_oracle(gpu, area_path):
     from ld_tools_amd import PackedPanel, ld_area, synth
     from oracle import c_oracle
 
@@ -418,6 +427,36 @@ def test_area_banded_against_oracle(gpu):
         lo = np.searchsorted(pos, np.maximum(pos[qs] - flank, 0), side="right")
         hi = np.searchsorted(pos, pos[qs] + flank, side="right")
         assert hits.n_pairs == int((hi - lo).sum() - (flank > 0) * len(qs))
+
+
+def test_area_paths_agree(gpu):
+    """The two ld_area kernels return the same hits, bit for bit, on a panel with clustered and duplicate positions,
+    missing codes, monomorphic SNPs, subset and full query lists, flank 0 and a threshold of 0."""
+    from ld_tools_amd import PackedPanel, ld_area, ops, synth
+
+    n, h = 2500, 5008
+    codes = synth.synth_codes_host(n, h, seed=21, miss=0.001)
+    codes[100] = 0                  # monomorphic REF
+    codes[101] = 1                  # monomorphic ALT
+    codes[102, ::3] = 2             # a third of the haplotypes missing
+    rng = np.random.RandomState(4)
+    pos = np.cumsum(rng.choice([0, 1, 3, 40, 400, 5000], size=n, p=[0.05, 0.2, 0.2, 0.3, 0.2, 0.05])) + 1
+    p = PackedPanel.from_codes(codes)
+    cases = [(None, 2000, "r_square", 0.5), (None, 0, "r_square", 0.0), (list(range(0, n, 3)), 30000, "d_prime", 0.95),
+             (list(rng.choice(n, 700, replace=False)), 800, "r_square", 0.0), (None, 10 ** 7, "r_square", 0.9)]
+    try:
+        for queries, flank, measure, thres in cases:
+            got = {}
+            for path in ("popcount", "mfma"):
+                ops.set_area_path(path)
+                hits = ld_area(p, pos, queries, flank, measure, thres)
+                got[path] = (hits.query.cpu().numpy(), hits.oppos.cpu().numpy(), hits.ld32.cpu().numpy().view(np.uint32),
+                             hits.n_pairs)
+            a, b = got["popcount"], got["mfma"]
+            assert a[3] == b[3] and len(a[0]) == len(b[0]), (flank, measure, thres, len(a[0]), len(b[0]))
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    finally:
+        ops.set_area_path("auto")
 
 
 # ------------------------------------------------------------------ calc_ld drop-in
