@@ -148,14 +148,21 @@ def ld_from_counts(n: int, n11, a1, r1, a2, r2, device: Optional[torch.device] =
 
 
 # --------------------------------------------------------------------------- area
-@dataclass
 class AreaHits:
     """Thresholded hits of a windowed scan, sorted by (query row, opposing row) = VCF order."""
 
-    query: torch.Tensor       # int64 [n]  panel row of var_1 (the query)
-    oppos: torch.Tensor       # int64 [n]  panel row of var_2 (the opposing variant)
-    ld32: torch.Tensor        # float32 [n, 2]  rounded (r_square, d_prime), -0.0 = int 0
-    n_pairs: int              # (query, opposing) pairs inside the windows that were evaluated
+    def __init__(self, query: torch.Tensor, oppos: torch.Tensor, ld32: torch.Tensor, n_pairs):
+        self.query = query        # int64 [n]  panel row of var_1 (the query)
+        self.oppos = oppos        # int64 [n]  panel row of var_2 (the opposing variant)
+        self.ld32 = ld32          # float32 [n, 2]  rounded (r_square, d_prime), -0.0 = int 0
+        self._n_pairs = n_pairs   # int, or a callable that counts on first use (bookkeeping only)
+
+    @property
+    def n_pairs(self) -> int:
+        """(query, opposing) pairs inside the windows that were evaluated."""
+        if callable(self._n_pairs):
+            self._n_pairs = self._n_pairs()
+        return self._n_pairs
 
     def __len__(self) -> int:
         return int(self.query.numel())
@@ -209,13 +216,15 @@ def ld_area(panel: PackedPanel, positions, queries: Optional[Sequence[int]] = No
     orow = hits[:, 1].to(torch.int64) & 0xFFFFFFFF
     order = torch.argsort(qrow * panel.n_snps + orow)
     ld32 = hits[:, 2:4].contiguous().view(torch.float32)[order]
-    # pairs evaluated = sum over queries of window population (bookkeeping for the bench, on device)
-    qpos = pos[q.to(torch.int64)]
-    lo = torch.searchsorted(pos, torch.clamp(qpos - flank, min=0), right=True)
-    hi = torch.searchsorted(pos, qpos + flank, right=True)
-    self_in = torch.clamp(qpos - flank, min=0) < qpos      # the query lies in its own window unless flank == 0
-    n_pairs = int((hi - lo).sum().item()) - int(self_in.sum().item())
-    return AreaHits(qrow[order], orow[order], ld32, n_pairs)
+    def count_pairs() -> int:
+        # pairs evaluated = sum over queries of window population (bookkeeping, on device, only when asked for)
+        qpos = pos[q.to(torch.int64)]
+        lo = torch.searchsorted(pos, torch.clamp(qpos - flank, min=0), right=True)
+        hi = torch.searchsorted(pos, qpos + flank, right=True)
+        self_in = torch.clamp(qpos - flank, min=0) < qpos      # the query lies in its own window unless flank == 0
+        return int((hi - lo).sum().item()) - int(self_in.sum().item())
+
+    return AreaHits(qrow[order], orow[order], ld32, count_pairs)
 
 
 # --------------------------------------------------------------------------- instrumentation
