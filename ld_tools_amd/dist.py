@@ -21,12 +21,16 @@ GROUP = 8
 
 
 def slab_partition(n_snps: int, world: int) -> List[Tuple[int, int]]:
-    """Rows [begin, end) packed by each rank: whole slabs, as even as possible, covering [0, n_snps)."""
+    """Rows [begin, end) packed by each rank: whole slabs, ceil(n_slabs / world) per rank until they run out
+    (only the last ranks get fewer, possibly none), covering [0, n_snps).  With this shape the rank-major
+    concatenation of equally padded shards IS the full tiled plane followed by padding, so the exchange needs no
+    per-rank placement (fused_gather)."""
     n_slabs = (n_snps + SLAB - 1) // SLAB
+    big = (n_slabs + world - 1) // world
     out = []
     for r in range(world):
-        s0 = n_slabs * r // world
-        s1 = n_slabs * (r + 1) // world
+        s0 = min(n_slabs, r * big)
+        s1 = min(n_slabs, (r + 1) * big)
         out.append((min(n_snps, s0 * SLAB), min(n_snps, s1 * SLAB)))
     return out
 
@@ -141,7 +145,15 @@ def fused_gather(full, local, slabs, slab_bytes: int, group=None, stage=None):
         rcnt8.view(world, big * cnt_bytes).copy_(shard[:, o_rcnt:o_ref])
         if with_ref:
             full["ref"].view(world, big * slab_bytes).copy_(shard[:, o_ref:])
-    else:
+    elif all(n == big for n in slabs[: max(1, (sum(slabs) + big - 1) // big) - 1]):
+        # slab_partition's shape (every rank but the last non-empty one holds `big` slabs): the rank-major
+        # concatenation of a piece is the full piece followed by padding -- two copies per piece, no per-rank loop
+        full["alt"].copy_(shard[:, :o_acnt].reshape(-1)[: full["alt"].numel()])
+        acnt8.copy_(shard[:, o_acnt:o_rcnt].reshape(-1)[: acnt8.numel()])
+        rcnt8.copy_(shard[:, o_rcnt:o_ref].reshape(-1)[: rcnt8.numel()])
+        if with_ref:
+            full["ref"].copy_(shard[:, o_ref:].reshape(-1)[: full["ref"].numel()])
+    else:                                          # arbitrary shard sizes: place rank by rank
         off = 0
         for r, n in enumerate(slabs):
             full["alt"][off * slab_bytes: (off + n) * slab_bytes] = shard[r, : n * slab_bytes]

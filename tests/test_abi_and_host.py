@@ -120,7 +120,11 @@ def test_slab_partition():
         for (b0, e0), (b1, e1) in zip(parts, parts[1:]):
             assert e0 == b1
         for b, e in parts[:-1]:
-            assert b % 128 == 0 and (e % 128 == 0 or e == n)
+            assert (b % 128 == 0 or b == n) and (e % 128 == 0 or e == n)
+        slabs = [(e - b + 127) // 128 for b, e in parts]
+        big = max(slabs)                      # every rank holds `big` slabs until they run out (fused_gather relies on it)
+        k = next((i for i, x in enumerate(slabs) if x < big), world)
+        assert all(x == big for x in slabs[:k]) and all(x == 0 for x in slabs[k + 1:])
 
 
 def test_synth_thresholds_and_positions():

@@ -378,6 +378,61 @@ def test_triangle_bench_size_against_oracle_rows(gpu, path):
     assert np.array_equal(n11[res.cell_index(rows, cols)], blk[:, :4096].ravel())
 
 
+def test_triangle_100k_shard_of_eight(gpu):
+    """configs[3] (100 000 x 5008 over 8 GPUs): the unit range rank 3 of 8 would own, on one card.  The two kernels
+    agree bit for bit on all 6.2e8 pairs of the shard, rows inside it match the C oracle, and the n11 mass of the
+    shard equals what the rectangular-block kernel counts for the same cells."""
+    import torch
+    from ld_tools_amd import PackedPanel, dist, ld_triangle, ops, synth
+    from ld_tools_amd._lib import UNIT_PAIRS
+    from oracle import c_oracle
+
+    n, h = 100000, 5008
+    codes_d = synth.synth_codes_device(n, h, seed=synth.BENCH_SEED)
+    p = PackedPanel.from_codes(codes_d)
+    u0, u1 = dist.unit_partition(n, 8)[3]
+    try:
+        ops.set_triangle_path("mfma")
+        a = ld_triangle(p, unit_range=(u0, u1), want_n11=True)
+        ops.set_triangle_path("popcount")
+        b = ld_triangle(p, unit_range=(u0, u1), want_n11=True)
+    finally:
+        ops.set_triangle_path("auto")
+    assert a.ld32.shape[0] == (u1 - u0) * UNIT_PAIRS
+    assert torch.equal(a.n11, b.n11)
+    assert torch.equal(a.ld32.view(torch.int32), b.ld32.view(torch.int32))
+    del b
+    # cells of a few rows that lie inside the shard, against the oracle
+    codes = codes_d.cpu().numpy()
+    o = c_oracle.Panel(codes)
+    npad = ((n + 127) // 128) * 128
+    G = npad // 8
+    checked = 0
+    for row in (61007, 61008, 70001, 99999):
+        cols = np.arange(row, dtype=np.int64)
+        t_ = cols // 128
+        u = t_ * G - 8 * t_ * (t_ - 1) + (row // 8 - 16 * t_)
+        m = (u >= u0) & (u < u1)
+        if not m.any():
+            continue
+        idx = (u[m] - u0) * UNIT_PAIRS + (row % 8) * 128 + (cols[m] % 128)
+        c = cols[m]
+        want_n = o.pair_counts(row, row + 1, int(c[0]), int(c[-1]) + 1)[0]        # the columns of a row's units are contiguous
+        assert len(want_n) == len(c)
+        k = len(c)
+        _, _, w_rsq, w_dp, w_flags = c_oracle.ld_from_counts_v(
+            h, want_n, np.full(k, o.acnt[row], np.uint32), np.full(k, o.rcnt[row], np.uint32), o.acnt[c], o.rcnt[c],
+            libm_pow=True)                                                            # var_1 = row, var_2 = column
+        got = a.ld32[torch.from_numpy(idx).to(a.ld32.device)].cpu().numpy()
+        got_n = a.n11[torch.from_numpy(idx).to(a.ld32.device)].cpu().numpy().view(np.uint32)
+        assert np.array_equal(got_n, want_n)
+        assert np.array_equal(k_of(got[:, 0]), np.rint(w_rsq * 1e4).astype(np.int64))
+        assert np.array_equal(k_of(got[:, 1]), np.rint(w_dp * 1e4).astype(np.int64))
+        assert np.array_equal(flags_of(got), w_flags)
+        checked += k
+    assert checked > 20000
+
+
 # ------------------------------------------------------------------ ld_area
 def test_area_matches_golden_drivers(gpu, area_path, drivers, panel_codes):
     from ld_tools_amd import PackedPanel, ld_area
