@@ -821,12 +821,17 @@ static int acquire_sched(hipStream_t s, uint32_t **sched)
             LDX_HIP(hipGetSymbolAddress(&sym, HIP_SYMBOL(g_sched)));
             sched_pool = reinterpret_cast<uint32_t (*)[2]>(sym);
         }
+        static uint32_t next_slot = 0;
+        static hipStream_t owner[kSchedSlots] = {};
         auto it = sched_slot.find(s);
-        if (it == sched_slot.end()) {
-            LDX_REQUIRE(sched_slot.size() < kSchedSlots, "more than 256 streams have launched ld_triangle in this process");
-            it = sched_slot.emplace(s, (uint32_t)sched_slot.size()).first;
+        if (it == sched_slot.end()) {   // a new stream takes the next slot round-robin; the slot's previous owner (a
+            slot = next_slot++ % kSchedSlots;   // stream last seen >= 256 new streams ago) loses its entry
+            if (next_slot > kSchedSlots) sched_slot.erase(owner[slot]);
+            owner[slot] = s;
+            sched_slot.emplace(s, slot);
+        } else {
+            slot = it->second;
         }
-        slot = it->second;
     }
     *sched = sched_pool[slot];
     LDX_HIP(hipMemsetAsync(*sched, 0, 2 * sizeof(uint32_t), s));

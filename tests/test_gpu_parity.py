@@ -378,6 +378,27 @@ def test_triangle_bench_size_against_oracle_rows(gpu, path):
     assert np.array_equal(n11[res.cell_index(rows, cols)], blk[:, :4096].ravel())
 
 
+def test_triangle_on_many_streams(gpu):
+    """The pass scheduler keeps one ticket-counter pair per stream in a pool of 256: more streams than that, used one
+    after another and two at a time, still give the single-stream result."""
+    import torch
+    from ld_tools_amd import PackedPanel, ld_triangle, synth
+
+    p = PackedPanel.from_codes(synth.synth_codes_device(300, 1008, seed=2))
+    ref = ld_triangle(p).ld32.clone()
+    torch.cuda.synchronize()
+    for k in range(300):
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        with torch.cuda.stream(s1):
+            o1 = ld_triangle(p)
+        with torch.cuda.stream(s2):
+            o2 = ld_triangle(p)
+        s1.synchronize()
+        s2.synchronize()
+        assert torch.equal(o1.ld32.view(torch.int32), ref.view(torch.int32)), k
+        assert torch.equal(o2.ld32.view(torch.int32), ref.view(torch.int32)), k
+
+
 def test_triangle_100k_shard_of_eight(gpu):
     """configs[3] (100 000 x 5008 over 8 GPUs): the unit range rank 3 of 8 would own, on one card.  The two kernels
     agree bit for bit on all 6.2e8 pairs of the shard, rows inside it match the C oracle, and the n11 mass of the
