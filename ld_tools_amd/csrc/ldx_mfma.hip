@@ -189,10 +189,14 @@ __global__ void __launch_bounds__(kMfmaThreads, 2)
 triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ fa, const double *__restrict__ fr,
                      const double *__restrict__ q, uint32_t n_snps, uint32_t n_slabs, uint32_t nchunks, double n,
                      double rn, uint64_t u_begin, uint64_t u_end, ldx_ld32 *__restrict__ out, ldx_ld64 *__restrict__ raw,
-                     uint32_t *__restrict__ n11, uint32_t p_begin, uint32_t p_end_arg, uint32_t *sched, int ablate_arg,
-                     unsigned long long *stamps, AreaArgs aa)
+                     uint32_t *__restrict__ n11, uint32_t p_begin, uint32_t p_end_arg, uint32_t n_short, uint32_t *sched,
+                     int ablate_arg, unsigned long long *stamps, AreaArgs aa)
 {
     const uint32_t p_end = kArea ? aa.pass_base[n_slabs] : p_end_arg;   // area: the plan kernel's total
+    // Tickets: first the passes [p_begin, p_end - n_short) whole, then each of the last n_short passes as TWO
+    // half-height tickets (rows 0..31 / 32..63 of the pass's four units): finer work items for the end of the
+    // launch, where whole passes leave the chip partly idle (see launch_mfma).
+    const uint32_t n_norm = p_end - p_begin - n_short, n_tickets = n_norm + 2u * n_short;
     // `ablate` (tuning builds only, -DLDX_TUNING + env LDX_ABLATE; a compile-time 0 in the product, so that
     // none of its tests survives as a branch): 1 = no epilogue arithmetic, 2 = one chunk instead of all (no
     // counting), 4 = no stores, 8 = no stagger, 64 = first half of the grid K loop only / second half epilogue
@@ -263,12 +267,13 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
     }
 
     uint64_t hit_slot = 0, hit_slot_end = 0;   // area: this wave's unfilled part of its current batch of hit slots
+    [[maybe_unused]] uint32_t pass_count = 0;
     uint32_t t_prev = 0xFFFFFFFFu;
     for (;;) {   // block-uniform: every wave reaches every barrier
         __syncthreads();   // the ticket is in LDS; every wave is past its previous epilogue (both B buffers free)
         const uint32_t ticket = tickets[parity];
         parity ^= 1u;
-        if (ticket >= p_end - p_begin) {   // block-uniform; the last workgroup out re-arms the counters
+        if (ticket >= n_tickets) {   // block-uniform; the last workgroup out re-arms the counters
             if (tid == 0 && atomicAdd(&sched[1], 1u) == gridDim.x - 1u) {
                 sched[1] = 0u;
                 __threadfence();
@@ -276,7 +281,10 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
             }
             break;
         }
-        const uint32_t p = p_begin + ticket;
+        ++pass_count;
+        const bool short_pass = ticket >= n_norm;                              // block-uniform
+        const uint32_t hsel = short_pass ? (ticket - n_norm) & 1u : 0u;        // which 32-row half
+        const uint32_t p = p_begin + (short_pass ? n_norm + ((ticket - n_norm) >> 1) : ticket);
         auto pbase = [&](uint32_t tile) { return kArea ? aa.pass_base[tile] : mfma_pass_base(tile, n_slabs); };
         uint32_t t;
         {
@@ -299,17 +307,19 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
         constexpr uint32_t kBStride = kSlab * 2u;   // uint2 per chunk
         const uint32_t b_off = (tid >> 1) * kBRow + (tid & 1u) * 64u;
 
-        {
+        auto pass_body = [&](auto mm_c) {
+            constexpr int MM = decltype(mm_c)::value;   // 32-row accumulator tiles per wave: 2 (a 64-row unit) or 1 (half)
             const uint64_t vv = pass + wave;
             const bool active = vv >= seg_begin && vv < seg_end;
             const uint32_t g64 = (uint32_t)((vv < te ? vv : pass) - tb) + 2u * t;   // a row group inside the panel either way
-            const uint32_t row0 = g64 * kRows64;
+            const uint32_t roff = MM == 1 ? 32u * hsel : 0u;                        // half-height: rows roff .. roff+31 of the unit
+            const uint32_t row0 = g64 * kRows64 + roff;
             // this lane's A rows: row0 + 32*m + l32 (both inside one slab: 64 | 128)
             const uint4 *ai = alt + ((size_t)(row0 / kSlab) * nchunks) * kSlab + (row0 % kSlab) + l32;
 
-            v16i acc[2][4];
+            v16i acc[MM][4];
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < MM; ++m)
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
@@ -334,9 +344,9 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                     bf[tt] = *reinterpret_cast<const v4i *>(buf + (32u * tt + l32) * kBRow + w * 32u + half * 16u);
 #endif
             };
-            auto mma8 = [&](const v4i (&af)[2], const v4i (&bf)[4]) {
+            auto mma8 = [&](const v4i (&af)[MM], const v4i (&bf)[4]) {
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
+                for (int m = 0; m < MM; ++m)
 #pragma unroll
                     for (int tt = 0; tt < 4; ++tt)
 #ifdef LDX_AB_NOMFMA
@@ -351,7 +361,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 // MFMAs wait on lgkmcnt
                 __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
+                for (int k = 0; k < 4 * MM; ++k) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x002, LDX_VALU_PER_MFMA, 0);
                 }
@@ -373,7 +383,11 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
             // sound: every asm load is followed, before the first C++ use of its register, by a wait that covers
             // it and by ring_touch(), which ties the register to that point of the program order; the ring is
             // statically indexed (chunk loop unrolled by 3), so no register with a load in flight is ever copied.
-            v4u ar[3][2];   // A words: ring slot k holds the chunk c with c % 3 == k
+            v4u ar[3][MM];   // A words: ring slot k holds the chunk c with c % 3 == k
+            auto touch_ring = [&](int k) {   // ties the slot's registers to this point of the program order
+                if constexpr (MM == 2) asm volatile("" : "+v"(ar[k][0]), "+v"(ar[k][1]));
+                else asm volatile("" : "+v"(ar[k][0]));
+            };
             v2u br[3];      // this thread's 8 bytes of the j-tile's chunk (B expansion share)
             auto clampc = [&](uint32_t c) { return c < nchunks ? c : nchunks - 1u; };   // surplus loads are discarded
             {
@@ -384,10 +398,12 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 for (int k = 0; k < 2; ++k) {
                     const v4u *src = reinterpret_cast<const v4u *>(ai + (size_t)clampc(k) * kSlab);
                     gload16(ar[k][0], src);
-                    gload16_512(ar[k][1], src);
+                    if constexpr (MM == 2) gload16_512(ar[k][1], src);
                 }
                 asm volatile("s_waitcnt vmcnt(0)");
-                asm volatile("" : "+v"(w0), "+v"(br[1]), "+v"(ar[0][0]), "+v"(ar[0][1]), "+v"(ar[1][0]), "+v"(ar[1][1]));
+                asm volatile("" : "+v"(w0), "+v"(br[1]));
+                touch_ring(0);
+                touch_ring(1);
                 v4i *d0 = reinterpret_cast<v4i *>(bexp + b_off);   // chunk 0 -> buffer 0
                 d0[0] = expand16(w0.x);
                 d0[1] = expand16(w0.x >> 16);
@@ -425,11 +441,15 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
             }
             __syncthreads();
             if (ablate & 256) __builtin_amdgcn_s_setprio(3);   // experiment: the K-loop wave outranks instead
+            if (ablate & 1024) {   // experiment: the two workgroups of a CU take turns being favoured in the K loop
+                if ((pass_count + (blockIdx.x >= (gridDim.x + 1) / 2 ? 1u : 0u)) & 1u) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+            }
             LDX_STAMP(1);
-            v4i af0[2], bf0[4], af1[2], bf1[4];
+            v4i af0[MM], bf0[4], af1[MM], bf1[4];
             read_bf(bf0, bexp, 0);
 #pragma unroll
-            for (int m = 0; m < 2; ++m) af0[m] = EXPAND_A(ar[0][m].x);
+            for (int m = 0; m < MM; ++m) af0[m] = EXPAND_A(ar[0][m].x);
 
             const uint32_t nch_run = (ablate & 2) ? 1u : nchunks;
 #ifdef LDX_CHUNK_STAMPS
@@ -451,13 +471,13 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 {                                                                                                  \
                     const v4u *src_ = reinterpret_cast<const v4u *>(ai + (size_t)c3 * kSlab);                      \
                     gload16(ar[FAR][0], src_);                                                                     \
-                    gload16_512(ar[FAR][1], src_);                                                                 \
+                    if constexpr (MM == 2) gload16_512(ar[FAR][1], src_);                                          \
                 })                                                                                                 \
-                asm volatile("s_waitcnt vmcnt(5)");                                                                \
+                asm volatile("s_waitcnt vmcnt(%0)" : : "n"(MM == 2 ? 5 : 3));   /* all but the 1 + MM newest pairs */ \
                 asm volatile("" : "+v"(br[NXT]));                                                                  \
                 /* step 0: MFMAs of (c,0); prepare (c,1); quarter 1 of this thread's share of B chunk c+1 */      \
                 read_bf(bf1, rd, 1);                                                                               \
-                _Pragma("unroll") for (int m = 0; m < 2; ++m) af1[m] = EXPAND_A(ar[CUR][m].y);               \
+                _Pragma("unroll") for (int m = 0; m < MM; ++m) af1[m] = EXPAND_A(ar[CUR][m].y);               \
                 bdst[1] = EXPAND_B(br[NXT].x >> 16);                                                               \
                 mma8(af0, bf0);                                                                                    \
                 interleave();                                                                                      \
@@ -465,7 +485,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 LDX_CSTAMP(1)                                                                                      \
                 /* step 1: MFMAs of (c,1); prepare (c,2); quarter 2 of the B share */                             \
                 read_bf(bf0, rd, 2);                                                                               \
-                _Pragma("unroll") for (int m = 0; m < 2; ++m) af0[m] = EXPAND_A(ar[CUR][m].z);               \
+                _Pragma("unroll") for (int m = 0; m < MM; ++m) af0[m] = EXPAND_A(ar[CUR][m].z);               \
                 bdst[2] = EXPAND_B(br[NXT].y);                                                                     \
                 mma8(af1, bf1);                                                                                    \
                 interleave();                                                                                      \
@@ -473,7 +493,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 LDX_CSTAMP(2)                                                                                      \
                 /* step 2: MFMAs of (c,2); prepare (c,3); quarter 3 of the B share */                             \
                 read_bf(bf1, rd, 3);                                                                               \
-                _Pragma("unroll") for (int m = 0; m < 2; ++m) af1[m] = EXPAND_A(ar[CUR][m].w);               \
+                _Pragma("unroll") for (int m = 0; m < MM; ++m) af1[m] = EXPAND_A(ar[CUR][m].w);               \
                 bdst[3] = EXPAND_B(br[NXT].y >> 16);                                                               \
                 mma8(af0, bf0);                                                                                    \
                 interleave();                                                                                      \
@@ -484,10 +504,11 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 /* step 3: MFMAs of (c,3); prepare (c+1,0) from the other buffer and the next A chunk, whose */   \
                 /* words must have landed; quarter 0 of the B share of chunk c+2 goes into the buffer of chunk c, */ \
                 /* which nobody reads any more.  Only this chunk's two A loads may still be in flight. */           \
-                asm volatile("s_waitcnt vmcnt(2)");                                                                \
-                asm volatile("" : "+v"(ar[NXT][0]), "+v"(ar[NXT][1]), "+v"(br[FAR]));                              \
+                asm volatile("s_waitcnt vmcnt(%0)" : : "n"(MM));                                                   \
+                touch_ring(NXT);                                                                                   \
+                asm volatile("" : "+v"(br[FAR]));                                                                  \
                 read_bf(bf0, wr, 0);                                                                               \
-                _Pragma("unroll") for (int m = 0; m < 2; ++m) af0[m] = EXPAND_A(ar[NXT][m].x);               \
+                _Pragma("unroll") for (int m = 0; m < MM; ++m) af0[m] = EXPAND_A(ar[NXT][m].x);               \
                 *reinterpret_cast<v4i *>(bexp + (c_ & 1u) * kBBuf + b_off) = EXPAND_B(br[FAR].x);                  \
                 mma8(af1, bf1);                                                                                    \
                 interleave();                                                                                      \
@@ -502,8 +523,10 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
 #undef LDX_CHUNK
             // drain the surplus loads of the last two chunks: their ring registers are about to be reused
             asm volatile("s_waitcnt vmcnt(0)");
-            asm volatile("" : "+v"(ar[0][0]), "+v"(ar[0][1]), "+v"(ar[1][0]), "+v"(ar[1][1]), "+v"(ar[2][0]), "+v"(ar[2][1]),
-                         "+v"(br[0]), "+v"(br[1]), "+v"(br[2]));
+            touch_ring(0);
+            touch_ring(1);
+            touch_ring(2);
+            asm volatile("" : "+v"(br[0]), "+v"(br[1]), "+v"(br[2]));
 
             if (ablate & 256) __builtin_amdgcn_s_setprio(0);
 #ifdef LDX_CHUNK_STAMPS
@@ -522,7 +545,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
             if (!(ablate & 16)) __builtin_amdgcn_s_setprio(3);
             if (!active) {   // wave-uniform; inactive waves only helped with B and the barriers
                 if (tid == 0) tickets[parity] = next_ticket;
-                continue;
+                return;
             }
             // epilogue: acc[m][tt][e] is 8 * n11 of pair (i, j) with
             //   i = row0 + 32*m + (e & 3) + 8*(e >> 2) + 4*half,  j = 128*t + 32*tt + l32
@@ -556,25 +579,25 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
 #endif
             for (int e = 0; e < 16; ++e) {
                 constexpr bool kClean = decltype(clean_c)::value;
-                // The eight pairs of this step (two rows x four column tiles) go through the epilogue WITHOUT
-                // branches -- invalid cells (row <= col, pad rows) are computed on whatever the registers hold and
-                // zeroed by a select -- so their eight dependent fp64 chains interleave: beside another wave's K
-                // loop an epilogue gets few issue slots and must not also wait on its own latencies.
-                uint32_t ri[2], cnt[2][4];
-                uint64_t us[2];
-                bool in_range[2], valid[2][4], slow[2][4];
-                ldx_ld32 res[2][4];
-                ldx_ld64 rw[2][4];
+                // The pairs of this step (MM rows x four column tiles) go through the epilogue WITHOUT branches --
+                // invalid cells (row <= col, pad rows) are computed on whatever the registers hold and zeroed by a
+                // select -- two at a time with their dependent fp64 chains interleaved (ld_multi_fast2): beside
+                // another wave's K loop an epilogue gets few issue slots and must not also wait on its own latencies.
+                uint32_t ri[MM], cnt[MM][4];
+                uint64_t us[MM];
+                bool in_range[MM], valid[MM][4], slow[MM][4];
+                ldx_ld32 res[MM][4];
+                ldx_ld64 rw[MM][4];
                 bool any_slow = false;
 #pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    ri[m] = 32u * m + (e & 3) + 8u * (e >> 2) + 4u * half;   // row inside the unit
-                    us[m] = vv * 8u + ri[m] / kGroup;                        // the small unit this row belongs to
+                for (int m = 0; m < MM; ++m) {
+                    ri[m] = 32u * m + (e & 3) + 8u * (e >> 2) + 4u * half;   // row inside this wave's tile(s)
+                    us[m] = vv * 8u + (ri[m] + roff) / kGroup;               // the small unit this row belongs to
                     in_range[m] = kClean || (us[m] >= u_begin && us[m] < u_end);
                 }
                 if (kRaw) {   // parity / debugging output: the op-for-op mirror, unrounded values kept
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) {
+                    for (int m = 0; m < MM; ++m) {
                         const uint32_t i = row0 + ri[m];
                         const double fa1 = __shfl(sfa, (int)ri[m]), fr1 = __shfl(sfr, (int)ri[m]), q1 = __shfl(sq, (int)ri[m]);
 #pragma unroll
@@ -588,59 +611,72 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                         }
                     }
                 } else {
-                    // Two chains at a time (the same column for both rows), staged: with 128 live accumulators there is
-                    // room for the operands and temporaries of two interleaved pairs, not four (hipcc then spills
-                    // accumulator tiles); operands come from LDS every step (4 + 8 ds_read_b128 per 16 pairs).
-                    FastRow fr2x[2];
+                    // Two chains at a time, staged: with 128 live accumulators there is room for the operands and
+                    // temporaries of two interleaved pairs, not four (hipcc then spills accumulator tiles).  A 64-row
+                    // unit pairs its two rows on one column (MM == 2), a half-height one two columns on its row;
+                    // operands come from LDS every step, the next pair's columns one pair ahead.
+                    FastRow fr2x[MM];
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) {
+                    for (int m = 0; m < MM; ++m) {
                         const d2 *rs = reinterpret_cast<const d2 *>(rstat + ri[m] * kStat);   // two addresses per wave: broadcast
                         const d2 r01 = rs[0], r23 = rs[1];
                         fr2x[m] = FastRow{r01.x, r01.y, r23.x, r23.y};
                     }
-                    const d2 *cs = reinterpret_cast<const d2 *>(cstat + l32 * kStat);
-                    d2 c01n = cs[0], c23n = cs[1];
+                    constexpr int kPairs = MM == 2 ? 4 : 2;
+                    auto chain_m = [](int, int k) { return MM == 2 ? k : 0; };
+                    auto chain_tt = [](int pp, int k) { return MM == 2 ? pp : 2 * pp + k; };
+                    auto load_col = [&](int tt) {
+                        const d2 *cs = reinterpret_cast<const d2 *>(cstat + (32u * tt + l32) * kStat);
+                        const d2 c01 = cs[0], c23 = cs[1];
+                        return FastCol{c01.x, c01.y, c23.x, c23.y};
+                    };
+                    FastCol nxt[2];
+                    nxt[0] = load_col(chain_tt(0, 0));
+                    nxt[1] = MM == 2 ? nxt[0] : load_col(chain_tt(0, 1));
 #pragma unroll
-                    for (int tt = 0; tt < 4; ++tt) {
-                        const d2 c01 = c01n, c23 = c23n;
-                        if (tt < 3) {   // the next column's operands: their LDS latency hides behind this column's arithmetic
-                            c01n = cs[(tt + 1) * (16 * kStat)];
-                            c23n = cs[(tt + 1) * (16 * kStat) + 1];
+                    for (int pp = 0; pp < kPairs; ++pp) {
+                        const FastCol fcx[2] = {nxt[0], nxt[1]};
+                        if (pp + 1 < kPairs) {   // the next pair's columns: their LDS latency hides behind this pair's arithmetic
+                            nxt[0] = load_col(chain_tt(pp + 1, 0));
+                            nxt[1] = MM == 2 ? nxt[0] : load_col(chain_tt(pp + 1, 1));
                         }
-                        const FastCol fcx[2] = {FastCol{c01.x, c01.y, c23.x, c23.y}, FastCol{c01.x, c01.y, c23.x, c23.y}};
+                        FastRow frk[2];
                         int a8[2];
                         ldx_ld32 r2[2];
                         bool s2[2];
 #pragma unroll
-                        for (int m = 0; m < 2; ++m) {
+                        for (int k = 0; k < 2; ++k) {
+                            const int m = chain_m(pp, k), tt = chain_tt(pp, k);
+                            frk[k] = fr2x[m];
                             const uint32_t i = row0 + ri[m], j = t * kSlab + 32u * tt + l32;
                             valid[m][tt] = kClean || ((i > j) && (i < n_snps));
 #ifdef LDX_AB_STATIC_E   // tuning: no register-indirect accumulator read (results wrong)
-                            a8[m] = acc[m][tt][0] + e;
+                            a8[k] = acc[m][tt][0] + e;
 #else
-                            a8[m] = acc[m][tt][e];
+                            a8[k] = acc[m][tt][e];
 #endif
-                            cnt[m][tt] = (uint32_t)a8[m] >> 3;
+                            cnt[m][tt] = (uint32_t)a8[k] >> 3;
                         }
                         if (ablate & 1) {   // tuning: no epilogue arithmetic
 #pragma unroll
-                            for (int m = 0; m < 2; ++m) {
-                                res[m][tt] = ldx_ld32{(float)a8[m], 0.0f};
-                                slow[m][tt] = false;
+                            for (int k = 0; k < 2; ++k) {
+                                res[chain_m(pp, k)][chain_tt(pp, k)] = ldx_ld32{(float)a8[k], 0.0f};
+                                slow[chain_m(pp, k)][chain_tt(pp, k)] = false;
                             }
                         } else {
-                            ld_multi_fast2<2, kClean>(a8, fk, fr2x, fcx, r2, s2);
+                            ld_multi_fast2<2, kClean>(a8, fk, frk, fcx, r2, s2);
 #pragma unroll
-                            for (int m = 0; m < 2; ++m) {
-                                res[m][tt] = r2[m];
-                                slow[m][tt] = s2[m] && valid[m][tt];
+                            for (int k = 0; k < 2; ++k) {
+                                const int m = chain_m(pp, k), tt = chain_tt(pp, k);
+                                res[m][tt] = r2[k];
+                                slow[m][tt] = s2[k] && valid[m][tt];
                                 any_slow = any_slow || slow[m][tt];
                             }
                         }
                     }
                     if (__builtin_expect(__any(any_slow), 0)) {   // near a rounding tie, Dn == 0, ...: the exact mirror
 #pragma unroll
-                        for (int m = 0; m < 2; ++m)
+                        for (int m = 0; m < MM; ++m)
 #pragma unroll
                             for (int tt = 0; tt < 4; ++tt)
                                 if (slow[m][tt]) {
@@ -650,12 +686,12 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                     }
                 }
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
+                for (int m = 0; m < MM; ++m)
                     if (in_range[m] && !(ablate & 4)) {
 #pragma unroll
                         for (int tt = 0; tt < 4; ++tt) {
                             const uint32_t jl = 32u * tt + l32;
-                            const size_t o = (size_t)(us[m] - u_begin) * LDX_UNIT_PAIRS + (size_t)(ri[m] % kGroup) * kSlab + jl;
+                            const size_t o = (size_t)(us[m] - u_begin) * LDX_UNIT_PAIRS + (size_t)((ri[m] + roff) % kGroup) * kSlab + jl;
                             ldx_ld32 w = res[m][tt];
                             if (!kClean && !valid[m][tt]) w = ldx_ld32{0.0f, 0.0f};
                             out[o] = w;
@@ -674,6 +710,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
             // ((fa1*fr1)*fa2)*fr2 associates in argument order), so a pair that needs the mirror
             // gets it once per order.
             auto area_epilogue = [&]() {
+              if constexpr (kArea && MM == 2) {
                 uint64_t slot = hit_slot, slot_end = hit_slot_end;
                 const float kthr = (float)aa.k_thres;
                 const bool prefilter = aa.k_thres > 2.0;
@@ -775,15 +812,16 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 }
                 hit_slot = slot;
                 hit_slot_end = slot_end;
+              }
             };
-            if (kArea) {
+            if constexpr (kArea) {
                 area_epilogue();
                 if (tid == 0) tickets[parity] = next_ticket;
                 if (!(ablate & 16)) __builtin_amdgcn_s_setprio(0);
-                continue;
+                return;
             }
             const bool clean = !kRaw && rows_ordinary && (cols_odd[0] | cols_odd[1]) == 0u &&
-                               row0 >= (t + 1u) * kSlab && row0 + kRows64 <= n_snps && (t + 1u) * kSlab <= n_snps &&
+                               row0 >= (t + 1u) * kSlab && row0 + 32u * MM <= n_snps && (t + 1u) * kSlab <= n_snps &&
                                vv * 8u >= u_begin && vv * 8u + 8u <= u_end;
             if (clean && !(ablate & 512)) epilogue(std::true_type{});
             else epilogue(std::false_type{});
@@ -798,6 +836,12 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 my_stamps[5] = __builtin_amdgcn_s_memtime();
             }
 #endif
+        };
+        if constexpr (kArea) {
+            pass_body(std::integral_constant<int, 2>{});
+        } else {
+            if (short_pass) pass_body(std::integral_constant<int, 1>{});
+            else pass_body(std::integral_constant<int, 2>{});
         }
     }
     if (kArea)   // the unused slots of this wave's last batch
@@ -866,8 +910,17 @@ static int launch_mfma(const void *alt, const double *fa, const double *fr, cons
     const uint32_t t0 = tile_of(v_begin), t1 = tile_of(v_end - 1u);
     const uint32_t p_begin = mfma_pass_base(t0, ns) + (uint32_t)((v_begin - base64(t0)) / kMfmaWaves);
     const uint32_t p_end = mfma_pass_base(t1, ns) + (uint32_t)((v_end - base64(t1) + kMfmaWaves - 1u) / kMfmaWaves);
-    uint64_t grid = (uint64_t)cus * (8u / kMfmaWaves);   // persistent: 8 waves per CU = two workgroups
-    if (grid > p_end - p_begin) grid = p_end - p_begin;
+    // The last passes go out as two half-height tickets each (32-row tiles: ~0.55 of a pass time for half the work),
+    // so that the launch does not end with whole passes on a few workgroups while the rest of the chip idles.
+    const uint64_t slots = (uint64_t)cus * (8u / kMfmaWaves);   // persistent: 8 waves per CU = two workgroups
+    const uint32_t n_pass = p_end - p_begin;
+    // Measured at 10 000 x 5008 (1580 passes on 512 workgroups): 128 halved passes -3 %, 256..384 -1 %, all +13 %.
+    // A launch of at most half a round (tiny panels) halves every pass: -20 % at 1000-2000 SNPs.
+    uint32_t n_short = 2ull * n_pass <= slots ? n_pass : (n_pass > slots ? (uint32_t)(slots / 4u) : 0u);
+    if (const char *env = getenv("LDX_SHORT"))   // tuning / tests: force the number of halved passes
+        n_short = (uint32_t)atoi(env) < n_pass ? (uint32_t)atoi(env) : n_pass;
+    uint64_t grid = slots;
+    if (grid > (uint64_t)n_pass + n_short) grid = (uint64_t)n_pass + n_short;
     if (grid < 1) grid = 1;
     uint32_t *sched = nullptr;
     if (int rc = acquire_sched(s, &sched)) return rc;
@@ -884,7 +937,7 @@ static int launch_mfma(const void *alt, const double *fa, const double *fr, cons
 #endif
     triangle_mfma_kernel<kRaw, kN11><<<(uint32_t)grid, kMfmaThreads, lds, s>>>(
         (const uint4 *)alt, fa, fr, q, n_snps, n_slabs(n_snps), nch, (double)n_hap, 1.0 / (double)n_hap, unit_begin,
-        unit_end, out, out_raw, out_n11, p_begin, p_end, sched, ablate, stamps, AreaArgs{});
+        unit_end, out, out_raw, out_n11, p_begin, p_end, n_short, sched, ablate, stamps, AreaArgs{});
     LDX_HIP(hipGetLastError());
 #ifdef LDX_TUNING
     if (stamps) {   // tuning only: synchronous; the file holds the stamps of the LAST launch
@@ -1012,7 +1065,7 @@ int area_mfma(const void *alt, const double *fa, const double *fr, const double 
     const uint64_t units = ldx_triangle_units(n_snps) / 8u;   // 64-row units of the full triangle
     triangle_mfma_kernel<false, false, true><<<(uint32_t)cus * 2u, kMfmaThreads, lds, s>>>(
         (const uint4 *)alt, fa, fr, q, n_snps, T, nch, (double)n_hap, 1.0 / (double)n_hap, 0, units * 8u, nullptr, nullptr,
-        nullptr, 0u, 0u, sched, 0, nullptr, aa);
+        nullptr, 0u, 0u, 0u, sched, 0, nullptr, aa);
     LDX_HIP(hipGetLastError());
     return LDX_OK;
 }

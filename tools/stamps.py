@@ -52,3 +52,14 @@ if len(cs) and st[:, 3].max() < passes - 2:
     for k, nm in enumerate(names):
         print(f"   {nm:14s} {np.median(d[:, k]):7.0f} {np.percentile(d[:, k], 95):7.0f}")
     print(f"   {'chunk total':14s} {np.median(cs[:, 5] - cs[:, 0]):7.0f}")
+
+# end-of-kernel balance from the constant-rate counter (s_memrealtime, 100 MHz, chip-wide)
+rt0, rt1 = st[:, 1].astype(np.int64), st[:, 4].astype(np.int64)
+span = (rt1.max() - rt0.min()) / 100.0
+ends = (rt1 - rt0.min()) / 100.0
+print(f"kernel span {span:.1f} us; wave end times (us): p5={np.percentile(ends,5):.1f} p25={np.percentile(ends,25):.1f} "
+      f"p50={np.percentile(ends,50):.1f} p75={np.percentile(ends,75):.1f} p95={np.percentile(ends,95):.1f} max={ends.max():.1f}")
+print(f"mean busy fraction of a wave slot: {np.mean((rt1 - rt0) / 100.0) / span:.3f}")
+for npass_ in sorted(set(st[:, 3].astype(int))):
+    sel = st[:, 3].astype(int) == npass_
+    print(f"   waves with {npass_} passes: {sel.sum():5d}  end time median {np.median(ends[sel]):.1f} us  max {ends[sel].max():.1f} us")
