@@ -378,6 +378,24 @@ def test_triangle_bench_size_against_oracle_rows(gpu, path):
     assert np.array_equal(n11[res.cell_index(rows, cols)], blk[:, :4096].ravel())
 
 
+def test_triangle_half_height_tickets_agree(gpu, monkeypatch):
+    """Whole passes, all passes halved (two 32-row tickets each) and a mix give identical results (LDX_SHORT forces the
+    number of halved passes; by default only tiny launches and the last quarter round of large ones are halved)."""
+    import torch
+    from ld_tools_amd import PackedPanel, ld_triangle, synth
+
+    for n, h, miss in [(3000, 5008, 0.0), (1111, 777, 0.01)]:
+        p = PackedPanel.from_codes(synth.synth_codes_device(n, h, seed=9, miss=miss))
+        got = []
+        for short in ("0", "1000000", "37"):
+            monkeypatch.setenv("LDX_SHORT", short)
+            r = ld_triangle(p, want_n11=True)
+            got.append((r.ld32.clone().view(torch.int32), r.n11.clone()))
+        monkeypatch.delenv("LDX_SHORT")
+        for a, b in got[1:]:
+            assert torch.equal(a, got[0][0]) and torch.equal(b, got[0][1])
+
+
 def test_triangle_on_many_streams(gpu):
     """The pass scheduler keeps one ticket-counter pair per stream in a pool of 256: more streams than that, used one
     after another and two at a time, still give the single-stream result."""
