@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--force-dist", action="store_true", help="run the sharded path (process group + all-gather) even at world 1")
     ap.add_argument("--cpu-sample-snps", type=int, default=320)
+    ap.add_argument("--no-graph", action="store_true", help="launch the steps eagerly instead of replaying a HIP graph")
     ap.add_argument("--path", default="auto", choices=("auto", "mfma", "popcount"),
                     help="kernel behind ld_triangle (auto = the int8 MFMA kernel; results are identical)")
     return ap.parse_args()
@@ -164,16 +165,43 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    # The K steps are K back-to-back launches of a 0.25 ms kernel (plus, for N > 1, the exchange's all-gather and a
+    # handful of small copies): a launch-bound inner loop, captured once into a HIP graph and replayed inside the
+    # timed region.  The kernel's duration is then (graph span - exchange share) / K from HIP events on the replay
+    # stream at N = 1; any failure to capture falls back to eager launches.
+    graph = None
+    if not args.no_graph and (not use_dist or args.backend == "nccl"):   # RCCL collectives capture; gloo ones do not
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for _ in range(args.steps):
+                    step()
+            g.replay()                      # one untimed replay (also proves the graph runs)
+            torch.cuda.synchronize()
+            graph = g
+        except Exception as exc:            # noqa: BLE001
+            print(f"[bench] HIP graph capture unavailable ({type(exc).__name__}: {exc}); eager launches", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+    fence()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(k)
+    if graph is not None:
+        ev0[0].record()
+        graph.replay()
+        ev1[0].record()
+    else:
+        for k in range(args.steps):
+            step(k)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    kern_ms = sum(a.elapsed_time(b_) for a, b_ in zip(ev0, ev1)) / args.steps
+    if graph is not None:
+        kern_ms = ev0[0].elapsed_time(ev1[0]) / args.steps
+    else:
+        kern_ms = sum(a.elapsed_time(b_) for a, b_ in zip(ev0, ev1)) / args.steps
     if world > 1:
         t = torch.tensor([kern_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -221,6 +249,7 @@ def main():
         "config": {"workload": f"ld_triangle {n_snps}x{n_hap}", "n_snps": n_snps, "n_hap": n_hap,
                    "pairs_per_step": n_pairs, "output": "8 B/pair (f32 r2, f32 D', rounded to 4 decimals) in HBM",
                    "kernel_path": "int8 MFMA counts + f64 epilogue" if mfma else "AND+popcount counts + f64 epilogue",
+                   "launch": "HIP graph of the K steps" if graph is not None else "eager",
                    "sharding": "none" if world == 1 else f"row-block shards, all-gather, pass list / {world}"},
         "roofline": roofline,
         "roofline_hbm": hbm,      # the metric's "% HBM roofline": output bytes + one read of the packed plane
@@ -229,6 +258,8 @@ def main():
         line["roofline_valu"] = {"bound": "valu-int", "achieved": lane_ops / kern_s / 1e12, "peak": VALU_PEAK_TLANEOPS,
                                  "unit": "T lane-ops/s", "frac": lane_ops / kern_s / 1e12 / VALU_PEAK_TLANEOPS,
                                  "ops_per_pair": 2 * math.ceil(n_hap / 32)}
+    if graph is not None and use_dist:   # the graph's span is all there is: the exchange rides in the per-step figure
+        roofline["kernel_ms_includes_exchange"] = True
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         need = max(args.cpu_sample_snps, 1536)
         host = codes_local[:need].cpu().numpy()
