@@ -11,4 +11,5 @@ as the VCF source; pysam itself is only imported by the command-line shells.
 from .area import AreaQueryResult, area_scan, get_inld_vars, write_area_file  # noqa: F401
 from .ingest import RaggedGenotypesError, codes_matrix, find_record, sample_genotypes  # noqa: F401
 from .lite import DifChrsError, NotInIntgenConvDbError, NotRsIdError, check_rs_id, ld_lite_table  # noqa: F401
-from .triangle import TriangleMatrix, create_matrix, triangle_matrix, write_triangle_table  # noqa: F401
+from .triangle import (TriangleMatrix, create_matrix, stream_triangle_table, triangle_matrix,  # noqa: F401
+                       write_triangle_table)

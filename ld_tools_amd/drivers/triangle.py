@@ -65,6 +65,48 @@ def write_triangle_table(path: str, m: TriangleMatrix, ld_measure: str, pop_name
             out.write(m.rs_ids_srtd[row_index] + "\t" + poss[row_index] + "\t" + line)
 
 
+_K_TEXT = None
+
+
+def _cell_text_table() -> np.ndarray:
+    """str() of every value a cell can hold with k = value * 10^4 in 0..10000: index k -> repr(k / 10^4), and one more
+    entry (index 10001) for the int 0."""
+    global _K_TEXT
+    if _K_TEXT is None:
+        _K_TEXT = np.array([str(k / 10000.0) for k in range(10001)] + ["0"], dtype=object)
+    return _K_TEXT
+
+
+def stream_triangle_table(path: str, chrom: str, rs_ids_srtd: Sequence[str], poss_srtd: Sequence[int], result,
+                          ld_measure: str, ld_low_thres: Optional[float], pop_names: Sequence[str],
+                          gend_names: Sequence[str], rows_per_block: int = 512) -> None:
+    """write_triangle_table for matrices too large to hold as Python lists: the same bytes, produced block of rows
+    by block of rows straight from the device result (``TriangleResult.dense(rows=...)``) through a 10 002-entry
+    text table instead of one Python float per cell.  A 10 000 x 10 000 matrix (~600 MB of text, which the
+    reference could never produce) takes tens of seconds, almost all of it string joining."""
+    tab = "\t"
+    poss = [str(p) for p in poss_srtd]
+    n = len(rs_ids_srtd)
+    table = _cell_text_table()
+    with open(path, "w") as out:
+        out.write(f"##General\tinfo:\t{ld_measure}\tchr{chrom}\t{tab.join(pop_names)}\t{tab.join(gend_names)}\n\n")
+        out.write("rsIDs\t\t" + "\t".join(rs_ids_srtd) + "\n")
+        out.write("\tPositions\t" + "\t".join(poss) + "\n")
+        for r0 in range(0, n, rows_per_block):
+            r1 = min(n, r0 + rows_per_block)
+            v = result.dense(ld_measure, ld_low_thres, rows=(r0, r1)).cpu().numpy()
+            k = np.rint(v.astype(np.float64) * 1e4).astype(np.int64)
+            int0 = np.signbit(v) & (v == 0)
+            big = k > 10000                                   # D' or r^2 above 1: only with missing codes; rare, formatted one by one
+            idx = np.where(int0, 10001, np.minimum(k, 10000))
+            text = table[idx]
+            if big.any():
+                for rr, cc in zip(*np.nonzero(big)):
+                    text[rr, cc] = str(k[rr, cc] / 10000.0)
+            for row_index in range(r0, r1):
+                out.write(rs_ids_srtd[row_index] + "\t" + poss[row_index] + "\t" + "\t".join(text[row_index - r0]) + "\n")
+
+
 def create_matrix(vcf_opener, data_by_chrs: dict, src_file_name: str, trg_top_dir_path: str,
                   sample_names: Sequence[str], ld_measure: str = "r_square", ld_low_thres: Optional[float] = None,
                   matrix_type: str = "table", pop_names: Sequence[str] = ("ALL",),

@@ -158,6 +158,25 @@ def test_triangle_driver_writes_reference_text(chrom6, tmp_path):
 
 
 @pytest.mark.gpu
+def test_streamed_triangle_table_equals_list_writer(chrom6, tmp_path):
+    """The block-streaming writer (for matrices too large for Python lists) writes the same bytes, including D' > 1
+    cells (a variant with missing calls) and the int-0 / 0.0 distinction."""
+    from ld_tools_amd import PackedPanel, ld_triangle
+    from ld_tools_amd.drivers import stream_triangle_table, triangle_matrix, write_triangle_table
+    from ld_tools_amd.drivers.ingest import codes_matrix, find_record, sample_genotypes
+    vcf, names, tri_rows, _ = chrom6
+    rows = sorted(tri_rows + [[vcf.records[5].pos, vcf.records[5].id]], key=lambda r: r[0])   # record 5 carries code-2 calls
+    for measure, thres in (("r_square", None), ("d_prime", 0.3)):
+        m = triangle_matrix(vcf, "6", rows, names, measure, thres)
+        a, b = tmp_path / f"a_{measure}.tsv", tmp_path / f"b_{measure}.tsv"
+        write_triangle_table(str(a), m, measure, ("ALL",), ("male", "female"))
+        panel = PackedPanel.from_codes(codes_matrix([sample_genotypes(find_record(vcf, "6", p, i), names) for p, i in rows]))
+        stream_triangle_table(str(b), "6", m.rs_ids_srtd, m.poss_srtd, ld_triangle(panel), measure, thres, ("ALL",),
+                              ("male", "female"), rows_per_block=5)
+        assert a.read_text() == b.read_text()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("ftype", ["tsv", "json", "rsids"])
 def test_area_driver_writes_reference_text(chrom6, tmp_path, ftype):
     from ld_tools_amd.drivers import get_inld_vars
