@@ -111,12 +111,6 @@ __device__ __forceinline__ v4i expand16_a(uint32_t word, uint32_t sel0, uint32_t
 #define EXPAND_B(x) expand16(x)
 #endif
 
-#ifdef LDX_AB_NOSTREAM   // every chunk re-reads chunk 0: the K loop without memory latency
-#define LDX_AB_CHUNK(c) ((c) & 0u)
-#else
-#define LDX_AB_CHUNK(c) (c)
-#endif
-
 // In-chunk stamps (build with -DLDX_CHUNK_STAMPS on top of -DLDX_TUNING): s_memtime at six points of ONE chunk
 // (index LDX_CHUNK_STAMPS) of a wave's second pass, kept in SGPRs and written after the K loop.  Issued by
 // inline asm so that hipcc does not drain lgkmcnt for them; an outstanding s_memtime only makes the compiler's
@@ -126,12 +120,6 @@ __device__ __forceinline__ v4i expand16_a(uint32_t word, uint32_t sel0, uint32_t
     if (c_ == (uint32_t)(LDX_CHUNK_STAMPS) && npass == 1) asm volatile("s_memtime %0" : "=s"(cst[k]));
 #else
 #define LDX_CSTAMP(k)
-#endif
-
-#ifdef LDX_AB_NOLOADS   // tuning: the K loop without its global loads (results wrong)
-#define LDX_AB_LOADS(...) (void)c3;
-#else
-#define LDX_AB_LOADS(...) __VA_ARGS__
 #endif
 
 __device__ __forceinline__ uint32_t word_of(const uint4 &v, int w)
@@ -161,12 +149,6 @@ __host__ __device__ inline uint32_t mfma_pass_base(uint32_t t, uint32_t n_slabs)
 constexpr uint32_t kSchedSlots = 256;
 __device__ uint32_t g_sched[kSchedSlots][2];
 
-// One "matrix pipe token" per physical CU (index from HW_ID / XCC_ID): the two workgroups that share a CU take
-// turns in the K loop, so one's epilogue (VALU) always runs beside the other's K loop (matrix pipe) instead of
-// K loop beside K loop and epilogue beside epilogue (measured ~1.5x the time per pass).  Speed only: the wait
-// is bounded, and a waiter that gives up simply proceeds (and its release re-arms the token).
-constexpr uint32_t kCuTokens = 4096;
-__device__ uint32_t g_cu_token[kCuTokens];
 
 // Arguments of the banded (ld_area) use of the kernel: the same passes, K loop and operand staging; the pass list is
 // cut to the units a window of +-flank can reach, and the epilogue turns every pair into up to two thresholded
@@ -199,11 +181,12 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
     const uint32_t n_norm = p_end - p_begin - n_short, n_tickets = n_norm + 2u * n_short;
     // `ablate` (tuning builds only, -DLDX_TUNING + env LDX_ABLATE; a compile-time 0 in the product, so that
     // none of its tests survives as a branch): 1 = no epilogue arithmetic, 2 = one chunk instead of all (no
-    // counting), 4 = no stores, 8 = no stagger, 64 = first half of the grid K loop only / second half epilogue
-    // only, 128 = only the first half of the grid works.  Results are wrong by design when it is non-zero.
+    // counting), 4 = no stores, 16 = no epilogue priority, 64 = first half of the grid K loop only / second half
+    // epilogue only, 128 = only the first half of the grid works, 512 = no clean-unit epilogue.  Results are wrong
+    // by design for bits 1, 2, 4, 64, 128.
 #ifdef LDX_TUNING
     int ablate = ablate_arg;
-    if (ablate_arg & 64) ablate = (blockIdx.x < (gridDim.x + 1) / 2) ? (5 | 8) : (2 | 8);
+    if (ablate_arg & 64) ablate = (blockIdx.x < (gridDim.x + 1) / 2) ? 5 : 2;
     if ((ablate_arg & 128) && blockIdx.x >= (gridDim.x + 1) / 2) return;
 #else
     constexpr int ablate = 0;
@@ -260,14 +243,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
     uint32_t parity = 0;
     if (tid == 0) tickets[0] = draw();
 
-    uint32_t *token = nullptr;
-    if (ablate & 32) {   // experiment (tuning builds): measured no better than free-running workgroups
-        const uint32_t hw = __builtin_amdgcn_s_getreg(63492), xcc = __builtin_amdgcn_s_getreg(63508);   // HW_ID, XCC_ID
-        token = &g_cu_token[((xcc & 0xFu) << 8) | ((hw >> 8) & 0xFFu)];   // XCC | SE | SH | CU
-    }
-
     uint64_t hit_slot = 0, hit_slot_end = 0;   // area: this wave's unfilled part of its current batch of hit slots
-    [[maybe_unused]] uint32_t pass_count = 0;
     uint32_t t_prev = 0xFFFFFFFFu;
     for (;;) {   // block-uniform: every wave reaches every barrier
         __syncthreads();   // the ticket is in LDS; every wave is past its previous epilogue (both B buffers free)
@@ -281,7 +257,6 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
             }
             break;
         }
-        ++pass_count;
         const bool short_pass = ticket >= n_norm;                              // block-uniform
         const uint32_t hsel = short_pass ? (ticket - n_norm) & 1u : 0u;        // which 32-row half
         const uint32_t p = p_begin + (short_pass ? n_norm + ((ticket - n_norm) >> 1) : ticket);
@@ -435,16 +410,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 dst[1] = d2{r.rr, r.rq_s};
                 if (kArea) dst[2] = i < n_snps ? d2{(double)aa.pos[i], (double)aa.is_query[i]} : d2{0.0, 0.0};
             }
-            if (token && tid == 0) {   // the CU's matrix-pipe token (bounded wait; see g_cu_token)
-                uint32_t polls = 0;
-                while (atomicCAS(token, 0u, 1u) != 0u && ++polls < 2048u) __builtin_amdgcn_s_sleep(16);
-            }
             __syncthreads();
-            if (ablate & 256) __builtin_amdgcn_s_setprio(3);   // experiment: the K-loop wave outranks instead
-            if (ablate & 1024) {   // experiment: the two workgroups of a CU take turns being favoured in the K loop
-                if ((pass_count + (blockIdx.x >= (gridDim.x + 1) / 2 ? 1u : 0u)) & 1u) __builtin_amdgcn_s_setprio(1);
-                else __builtin_amdgcn_s_setprio(0);
-            }
             LDX_STAMP(1);
             v4i af0[MM], bf0[4], af1[MM], bf1[4];
             read_bf(bf0, bexp, 0);
@@ -463,16 +429,16 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 const unsigned char *rd = bexp + (c_ & 1u) * kBBuf;                                                \
                 unsigned char *wr = bexp + ((c_ + 1u) & 1u) * kBBuf;                                               \
                 v4i *bdst = reinterpret_cast<v4i *>(wr + b_off);                                                   \
-                const uint32_t c3 = LDX_AB_CHUNK(clampc(c_ + 2u));                                                 \
+                const uint32_t c3 = clampc(c_ + 2u);                                                               \
                 LDX_CSTAMP(0)                                                                                      \
                 /* loads of chunk c+2, B bits FIRST (vmcnt counts in issue order).  In flight now, oldest first: */ \
                 /* chunk c+1's {B, A, A} and this batch's {B, A, A}; step 0 needs the former B: 5 may stay */       \
-                LDX_AB_LOADS(gload8(br[FAR], bsrc + (size_t)c3 * kBStride);                                         \
+                gload8(br[FAR], bsrc + (size_t)c3 * kBStride);                                                     \
                 {                                                                                                  \
                     const v4u *src_ = reinterpret_cast<const v4u *>(ai + (size_t)c3 * kSlab);                      \
                     gload16(ar[FAR][0], src_);                                                                     \
                     if constexpr (MM == 2) gload16_512(ar[FAR][1], src_);                                          \
-                })                                                                                                 \
+                }                                                                                                  \
                 asm volatile("s_waitcnt vmcnt(%0)" : : "n"(MM == 2 ? 5 : 3));   /* all but the 1 + MM newest pairs */ \
                 asm volatile("" : "+v"(br[NXT]));                                                                  \
                 /* step 0: MFMAs of (c,0); prepare (c,1); quarter 1 of this thread's share of B chunk c+1 */      \
@@ -528,14 +494,12 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
             touch_ring(2);
             asm volatile("" : "+v"(br[0]), "+v"(br[1]), "+v"(br[2]));
 
-            if (ablate & 256) __builtin_amdgcn_s_setprio(0);
 #ifdef LDX_CHUNK_STAMPS
             asm volatile("s_waitcnt lgkmcnt(0)");
             if (my_stamps && lane == 0 && npass == 1)
                 for (int k = 0; k < 6; ++k) my_stamps[6 + 4 * (kStampPasses - 2) + k] = cst[k];   // slots of passes 38, 39
 #endif
             LDX_STAMP(2);
-            if (token && tid == 0) __hip_atomic_store(token, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // the next pass's ticket: drawn here (after the K loop's hand-counted loads), stored to LDS after the
             // epilogue, so the atomic's latency hides behind it
             uint32_t next_ticket = 0;
@@ -572,11 +536,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
             // The e-loop is NOT unrolled: 128 pairs x ~50 instructions would be ~50 KB of straight-line code
             // per wave, most of the instruction cache two CUs share.  acc[..][..][e] with a wave-uniform e
             // is a register-indirect move (s_set_gpr_idx_on), not scratch.
-#ifdef LDX_AB_UNROLL_E
-#pragma unroll
-#else
 #pragma unroll 1
-#endif
             for (int e = 0; e < 16; ++e) {
                 constexpr bool kClean = decltype(clean_c)::value;
                 // The pairs of this step (MM rows x four column tiles) go through the epilogue WITHOUT branches --
@@ -650,11 +610,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                             frk[k] = fr2x[m];
                             const uint32_t i = row0 + ri[m], j = t * kSlab + 32u * tt + l32;
                             valid[m][tt] = kClean || ((i > j) && (i < n_snps));
-#ifdef LDX_AB_STATIC_E   // tuning: no register-indirect accumulator read (results wrong)
-                            a8[k] = acc[m][tt][0] + e;
-#else
                             a8[k] = acc[m][tt][e];
-#endif
                             cnt[m][tt] = (uint32_t)a8[k] >> 3;
                         }
                         if (ablate & 1) {   // tuning: no epilogue arithmetic
