@@ -378,6 +378,44 @@ def test_triangle_bench_size_against_oracle_rows(gpu, path):
     assert np.array_equal(n11[res.cell_index(rows, cols)], blk[:, :4096].ravel())
 
 
+def test_triangle_random_shapes_both_kernels_and_oracle(gpu):
+    """Forty seeded random shapes (1..1400 SNPs, 1..2600 haplotypes, with and without missing codes and monomorphic
+    rows): the two kernels agree bit for bit on every cell, and the MFMA kernel equals the C oracle on all of them."""
+    import torch
+    from ld_tools_amd import PackedPanel, ld_triangle, ops, synth
+    from oracle import c_oracle
+
+    rng = np.random.RandomState(2026)
+    try:
+        for case in range(40):
+            n = int(rng.choice([1, 2, 3, 63, 64, 65, 127, 128, 129, 200, 255, 256, 257, 500, 777, 1025, 1400]))
+            h = int(rng.choice([1, 2, 31, 32, 33, 127, 128, 129, 500, 1008, 1023, 1025, 2600]))
+            miss = float(rng.choice([0.0, 0.0, 0.003, 0.05]))
+            codes = synth.synth_codes_host(n, h, seed=1000 + case, miss=miss)
+            if n > 4 and rng.rand() < 0.5:
+                codes[rng.randint(n)] = rng.randint(2)          # a monomorphic row
+            p = PackedPanel.from_codes(codes)
+            got = {}
+            for path in ("mfma", "popcount"):
+                ops.set_triangle_path(path)
+                r = ld_triangle(p, want_n11=True)
+                got[path] = (r.ld32.clone().view(torch.int32), r.n11.clone(), r)
+            assert torch.equal(got["mfma"][0], got["popcount"][0]) and torch.equal(got["mfma"][1], got["popcount"][1]), (n, h, miss)
+            if n >= 2:
+                rows, cols = np.tril_indices(n, -1)
+                res = got["mfma"][2]
+                idx = res.cell_index(rows, cols)
+                o = c_oracle.Panel(codes).triangle(libm_pow=True, want=("n11", "rsq_rnd", "dp_rnd", "flags"))
+                ld32 = res.ld32.cpu().numpy()[idx]
+                assert np.array_equal(res.n11.cpu().numpy().view(np.uint32)[idx], o["n11"][rows, cols]), (n, h, miss)
+                ok = (o["rsq_rnd"][rows, cols] < 1000) & (o["dp_rnd"][rows, cols] < 1000)
+                assert np.array_equal(k_of(ld32[ok, 0]), np.rint(o["rsq_rnd"][rows, cols][ok] * 1e4).astype(np.int64)), (n, h, miss)
+                assert np.array_equal(k_of(ld32[ok, 1]), np.rint(o["dp_rnd"][rows, cols][ok] * 1e4).astype(np.int64)), (n, h, miss)
+                assert np.array_equal(flags_of(ld32), o["flags"][rows, cols]), (n, h, miss)
+    finally:
+        ops.set_triangle_path("auto")
+
+
 def test_triangle_half_height_tickets_agree(gpu, monkeypatch):
     """Whole passes, all passes halved (two 32-row tickets each) and a mix give identical results (LDX_SHORT forces the
     number of halved passes; by default only tiny launches and the last quarter round of large ones are halved)."""
