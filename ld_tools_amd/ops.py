@@ -184,6 +184,8 @@ def ld_area(panel: PackedPanel, positions, queries: Optional[Sequence[int]] = No
     pos = pos.to(dev, dtype=torch.int64).contiguous()
     if pos.numel() != panel.n_snps:
         raise _lib.LdxError("positions must have one entry per SNP")
+    if pos.numel() > 1 and bool((pos[1:] < pos[:-1]).any().item()):
+        raise _lib.LdxError("positions must ascend (VCF order): the window search is a binary search")
     if queries is None:
         q = torch.arange(panel.n_snps, dtype=torch.int32, device=dev)
     else:

@@ -561,6 +561,16 @@ def test_area_banded_against_oracle(gpu, area_path):
         assert hits.n_pairs == int((hi - lo).sum() - (flank > 0) * len(qs))
 
 
+def test_area_rejects_unsorted_positions(gpu):
+    from ld_tools_amd import LdxError, PackedPanel, ld_area, synth
+
+    p = PackedPanel.from_codes(synth.synth_codes_host(10, 64, seed=1))
+    with pytest.raises(LdxError):
+        ld_area(p, [5, 4, 6, 7, 8, 9, 10, 11, 12, 13], None, 10)
+    with pytest.raises(LdxError):
+        ld_area(p, [1, 2, 3], None, 10)
+
+
 def test_area_paths_agree(gpu):
     """The two ld_area kernels return the same hits, bit for bit, on a panel with clustered and duplicate positions,
     missing codes, monomorphic SNPs, subset and full query lists, flank 0 and a threshold of 0."""
