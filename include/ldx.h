@@ -165,7 +165,7 @@ int ldx_area_dev(const void *alt, const double *fa, const double *fr, const doub
                  double thres, ldx_hit *hits, uint64_t hit_cap, uint64_t *n_hits, void *workspace,
                  size_t workspace_bytes, void *stream);
 size_t ldx_area_workspace_bytes(uint32_t n_snps, uint32_t n_hap, uint32_t n_query);
-/* kernel behind ldx_area_dev: LDX_PATH_AUTO (matrix-pipe band when >= 1/4 of the SNPs are queries, popcount scan
+/* kernel behind ldx_area_dev: LDX_PATH_AUTO (matrix-pipe band when >= 1/16 of the SNPs are queries, popcount scan
  * otherwise), LDX_PATH_POPCOUNT, LDX_PATH_MFMA; the hit sets are identical */
 int ldx_set_area_path(int path);
 int ldx_get_area_path(void);

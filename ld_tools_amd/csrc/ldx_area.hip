@@ -225,8 +225,9 @@ area_scan_kernel(const uint4 *__restrict__ alt, const uint4 *__restrict__ qalt, 
 
 using namespace ldx;
 
-// which kernel runs ld_area: LDX_PATH_AUTO = the matrix-pipe band when at least a quarter of the SNPs are queries
-// (it evaluates every pair of the band once for both orders), the popcount scan of query rows otherwise
+// which kernel runs ld_area: LDX_PATH_AUTO = the matrix-pipe band when at least 1/16 of the SNPs are queries (it
+// evaluates every pair of the band once for both orders, whatever the query list: 0.52 ms at 100k SNPs, +-1000
+// neighbours, against 8.2 ms x (queries / SNPs) for the popcount scan), the scan of query rows otherwise
 static int g_area_path = LDX_PATH_AUTO;
 
 extern "C" int ldx_set_area_path(int path)
@@ -264,7 +265,7 @@ extern "C" int ldx_area_dev(const void *alt, const double *fa, const double *fr,
     LDX_REQUIRE(workspace_bytes >= need && workspace_bytes >= area_mfma_workspace_bytes(n_snps),
                 "workspace too small (see ldx_area_workspace_bytes)");
     hipStream_t s = (hipStream_t)stream;
-    if (g_area_path == LDX_PATH_MFMA || (g_area_path == LDX_PATH_AUTO && (uint64_t)n_query * 4u >= n_snps && n_snps >= 2))
+    if (g_area_path == LDX_PATH_MFMA || (g_area_path == LDX_PATH_AUTO && (uint64_t)n_query * 16u >= n_snps && n_snps >= 2))
         return area_mfma(alt, fa, fr, q, n_snps, n_hap, positions, queries, n_query, flank, measure, thres, hits, hit_cap,
                          n_hits, workspace, s);
     const uint32_t qpad = ldx_padded_snps(n_query), T = ldx::n_slabs(n_snps), nch = ldx::n_chunks(n_hap);

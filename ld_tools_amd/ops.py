@@ -36,7 +36,7 @@ def get_triangle_path() -> str:
 
 def set_area_path(name: str) -> None:
     """Choose the kernel behind ld_area: 'popcount' (scan of the query rows), 'mfma' (the whole +-flank band on the
-    matrix pipe) or 'auto' (mfma when at least a quarter of the SNPs are queries).  The hit sets are identical."""
+    matrix pipe) or 'auto' (mfma when at least 1/16 of the SNPs are queries).  The hit sets are identical."""
     check(lib.ldx_set_area_path(PATHS[name]), "ldx_set_area_path")
 
 
