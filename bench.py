@@ -37,8 +37,8 @@ VALU_PEAK_TLANEOPS = 256 * 64 * 2.4e9 / 1e12   # AND / BCNT have no packed form:
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--snps", type=int, default=0, help="panel size (default: 10000 * sqrt(gpus))")
     ap.add_argument("--haps", type=int, default=5008)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -183,6 +183,8 @@ def main():
             print(f"[bench] HIP graph capture unavailable ({type(exc).__name__}: {exc}); eager launches", file=sys.stderr)
             graph = None
             torch.cuda.synchronize()
+    if out is not None:
+        out.ld32.fill_(float("nan"))       # the timed steps must produce every result again (checked below)
     fence()
     t0 = time.perf_counter()
     if graph is not None:
@@ -206,6 +208,13 @@ def main():
         t = torch.tensor([kern_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         kern_ms = float(t.item())
+
+    # the output of the timed region against a separately computed result: nothing was skipped or left stale
+    check = ld_triangle(panel, unit_range=(u0, u1))
+    torch.cuda.synchronize()
+    if not torch.equal(check.ld32.view(torch.int32), out.ld32.view(torch.int32)):
+        raise SystemExit("bench.py: the timed steps did not reproduce the triangle (stale or skipped work)")
+    del check
 
     value = n_pairs * args.steps / dt
     # ---- roofline of the dominant kernel, per launch, this rank's share ----
@@ -249,7 +258,7 @@ def main():
         "config": {"workload": f"ld_triangle {n_snps}x{n_hap}", "n_snps": n_snps, "n_hap": n_hap,
                    "pairs_per_step": n_pairs, "output": "8 B/pair (f32 r2, f32 D', rounded to 4 decimals) in HBM",
                    "kernel_path": "int8 MFMA counts + f64 epilogue" if mfma else "AND+popcount counts + f64 epilogue",
-                   "launch": "HIP graph of the K steps" if graph is not None else "eager",
+                   "launch": "HIP graph of the K steps, output verified after the timed region" if graph is not None else "eager",
                    "sharding": "none" if world == 1 else f"row-block shards, all-gather, pass list / {world}"},
         "roofline": roofline,
         "roofline_hbm": hbm,      # the metric's "% HBM roofline": output bytes + one read of the packed plane
