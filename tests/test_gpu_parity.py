@@ -601,6 +601,40 @@ def test_area_paths_agree(gpu):
         ops.set_area_path("auto")
 
 
+def test_area_random_cases_both_kernels_and_oracle(gpu):
+    """Seeded sweep over ragged shapes (1 SNP, 1 haplotype, sizes either side of the 128-wide tiles), clustered and repeated
+    positions, random flanks / thresholds / query subsets: both ld_area kernels against the C oracle's window loop."""
+    from ld_tools_amd import PackedPanel, ld_area, ops, synth
+    from oracle import c_oracle
+
+    rng = np.random.RandomState(77)
+    shapes = [(1, 64), (2, 1), (63, 37), (129, 129), (300, 1008), (513, 2504), (640, 128), (257, 5008)]
+    try:
+        for case, (n, h) in enumerate(shapes * 2):
+            codes = synth.synth_codes_host(n, h, seed=100 + case, miss=0.003 if case % 2 else 0.0)
+            pos = np.cumsum(rng.choice([0, 1, 2, 50, 700], size=n, p=[0.1, 0.3, 0.2, 0.3, 0.1])) + 1
+            flank = int(rng.choice([0, 1, 5, 120, 3000, 10 ** 6]))
+            measure = "r_square" if rng.rand() < 0.5 else "d_prime"
+            thres = float(rng.choice([0.0, 0.3, 0.8, 1.0]))
+            queries = None if rng.rand() < 0.5 else sorted(rng.choice(n, max(1, n // 3), replace=False).tolist())
+            p = PackedPanel.from_codes(codes)
+            o = c_oracle.Panel(codes)
+            qs = np.arange(n) if queries is None else np.array(queries)
+            hq, ho, hr, hd, hf = o.area(pos, qs, flank, 0 if measure == "r_square" else 1, thres, libm_pow=True)
+            for path in ("popcount", "mfma"):
+                ops.set_area_path(path)
+                hits = ld_area(p, pos, queries, flank, measure, thres)
+                tag = (case, n, h, flank, measure, thres, path)
+                assert len(hits) == len(hq), tag
+                assert np.array_equal(hits.query.cpu().numpy(), hq) and np.array_equal(hits.oppos.cpu().numpy(), ho), tag
+                ld = hits.ld32.cpu().numpy().reshape(-1, 2)
+                assert np.array_equal(k_of(ld[:, 0]), np.rint(hr * 1e4).astype(np.int64)), tag
+                assert np.array_equal(k_of(ld[:, 1]), np.rint(hd * 1e4).astype(np.int64)), tag
+                assert np.array_equal(flags_of(ld), hf), tag
+    finally:
+        ops.set_area_path("auto")
+
+
 # ------------------------------------------------------------------ calc_ld drop-in
 def test_calc_ld_dropin(gpu, kat):
     from ld_tools_amd.backend.calc_ld import calc_ld, calc_ld_full
