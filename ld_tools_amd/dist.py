@@ -1,4 +1,4 @@
-"""Multi-GPU sharding of the ld_triangle pair loop: one process per GPU, torch.distributed.
+"""Multi-GPU sharding of the ld_triangle pair loop and the ld_area window loop: one process per GPU, torch.distributed.
 
 The pair matrix has no cross-pair dependency (every cell needs rows i and j only), so the work
 shards without a data-path reduction.  What IS exchanged is the packed panel: each rank packs
@@ -8,6 +8,9 @@ count vectors gives every rank the full ALT plane.  Slab images are contiguous i
 layout, so the gathered buffer IS the full plane -- no re-layout.  Each rank then computes a
 contiguous, equal share of the triangle's work units (equal pair counts by construction; unit
 u's results live at (u - unit_begin) * 1024 of the rank's own output).
+
+ld_area shards by query: every rank scans a contiguous range of the query list against the full panel
+(query_partition balances window populations) and the sparse hit lists are all-gathered afterwards (gather_hits).
 
 Backend "nccl" is RCCL over xGMI on ROCm; "gloo" (CPU tensors) is used by the tests of the
 partition logic.
@@ -194,3 +197,77 @@ def all_gather_panel(local, n_snps: int, n_hap: int, group=None, out=None, with_
     full._gather_stage = fused_gather(fd, ld, slabs, slab_bytes, group, getattr(full, "_gather_stage", None))
     full.refresh_stats()
     return full
+
+
+# --------------------------------------------------------------------------- ld_area
+def query_partition(positions, queries, flank: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous ranges [begin, end) of the ASCENDING query list per rank, cut so that every rank gets a near-equal
+    number of (query, opposing) pairs: the cost of a query is its window population (ld_area.py:174-177,215-217),
+    which varies with the local SNP density, so equal query counts would not balance.  Ranges tile [0, n_query) in
+    rank order, hence the concatenation of the ranks' hit lists in rank order is the single-process hit list."""
+    import numpy as np
+
+    pos = np.asarray(positions, dtype=np.int64)
+    q = np.arange(pos.size, dtype=np.int64) if queries is None else np.sort(np.asarray(queries, dtype=np.int64))
+    if q.size == 0:
+        return [(0, 0)] * world
+    qpos = pos[q]
+    lo = np.searchsorted(pos, np.maximum(qpos - flank, 0), side="right")
+    hi = np.searchsorted(pos, qpos + flank, side="right")
+    cost = np.cumsum((hi - lo).astype(np.int64) + 1)                 # +1: a query with an empty window still costs a visit
+    cuts = [0]
+    for r in range(1, world):
+        cuts.append(max(cuts[-1], int(np.searchsorted(cost, cost[-1] * r // world, side="left"))))
+    cuts.append(int(q.size))
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+def gather_hits(query, oppos, ld32, group=None):
+    """All-gather the ranks' hit lists (variable length) in rank order: counts first, then ONE padded all-gather of
+    16-byte records {query row, opposing row, r_square bits, d_prime bits}.  Works with device tensors (RCCL) and CPU
+    tensors (gloo).  Returns (query int64 [n], oppos int64 [n], ld32 float32 [n, 2]) over all ranks."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    dev = query.device
+    n_mine = int(query.numel())
+    counts = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts, torch.tensor([n_mine], dtype=torch.int64, device=dev), group=group)
+    sizes = [int(c) for c in counts.tolist()]
+    rec = torch.empty((n_mine, 4), dtype=torch.int32, device=dev)
+    rec[:, 0] = query.to(torch.int32)
+    rec[:, 1] = oppos.to(torch.int32)
+    rec[:, 2:4] = ld32.reshape(n_mine, 2).contiguous().view(torch.int32)
+    total = sum(sizes)
+    out = torch.empty(total * 4, dtype=torch.int32, device=dev)
+    if total:
+        gather_shards(out, rec.reshape(-1), [4 * s for s in sizes], group)
+    out = out.view(total, 4)
+    return out[:, 0].to(torch.int64), out[:, 1].to(torch.int64), out[:, 2:4].contiguous().view(torch.float32)
+
+
+def ld_area_sharded(panel, positions, queries=None, flank: int = 100000, measure: str = "r_square", thres: float = 0.8,
+                    group=None, gather: bool = True):
+    """ld_area over all ranks: every rank holds the full panel (all_gather_panel) and scans ITS range of the query list
+    (query_partition); no data-path exchange during the scan.  With ``gather`` the hit lists are then all-gathered
+    (gather_hits) and every rank returns the complete AreaHits, identical to the single-GPU ld_area; without it each
+    rank keeps its own hits (the writers of ld_area.py:261-292 are per query, so a rank can write its own files)."""
+    import numpy as np
+    import torch.distributed as dist
+
+    from .ops import AreaHits, ld_area
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    pos = np.asarray(positions.cpu() if hasattr(positions, "cpu") else positions, dtype=np.int64)
+    q = np.arange(pos.size, dtype=np.int64) if queries is None else np.sort(np.asarray(queries, dtype=np.int64))
+    b, e = query_partition(pos, q, flank, world)[rank]
+    mine = ld_area(panel, positions, q[b:e].tolist(), flank, measure, thres)
+    if not gather:
+        return mine
+    qa, oa, la = gather_hits(mine.query, mine.oppos, mine.ld32, group)
+    lo = np.searchsorted(pos, np.maximum(pos[q] - flank, 0), side="right") if q.size else np.zeros(0, np.int64)
+    hi = np.searchsorted(pos, pos[q] + flank, side="right") if q.size else np.zeros(0, np.int64)
+    n_pairs = int((hi - lo).sum()) - (int((np.maximum(pos[q] - flank, 0) < pos[q]).sum()) if q.size else 0)
+    return AreaHits(qa, oa, la, n_pairs)

@@ -92,6 +92,18 @@ def main():
         pairs = torch.tensor([len(rows)], dtype=torch.int64)
         dist.all_reduce(pairs)
         assert int(pairs) == n_snps * (n_snps - 1) // 2
+    # ld_area hit lists: variable-length shards (one of them empty) gathered in rank order
+    for sizes in ([5, 0], [3, 11], [0, 0], [7, 7]):
+        k = sizes[rank]
+        base = sum(sizes[:rank])
+        q = torch.arange(base, base + k, dtype=torch.int64)
+        o = q * 3 + 1
+        ld = torch.stack([q.to(torch.float32) * 1e-4, -torch.zeros(k)], dim=1)     # -0.0 = the reference's int 0
+        gq, go, gl = ldist.gather_hits(q, o, ld)
+        tot = sum(sizes)
+        assert torch.equal(gq, torch.arange(tot, dtype=torch.int64)) and torch.equal(go, gq * 3 + 1)
+        assert gl.shape == (tot, 2) and torch.equal(gl[:, 0], gq.to(torch.float32) * 1e-4)
+        assert bool(torch.signbit(gl[:, 1]).all()) and bool((gl[:, 1] == 0).all())
     dist.barrier()
     if rank == 0:
         print("GLOO_OK")

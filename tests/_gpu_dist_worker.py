@@ -44,6 +44,23 @@ def main():
         assert torch.equal(part.n11, full.n11[u0 * UNIT_PAIRS: u1 * UNIT_PAIRS]), "shard counts"
         with_ref = ldist.all_gather_panel(local, n_snps, n_hap, with_ref=True)
         assert torch.equal(with_ref.ref, whole.ref), "gathered REF plane"
+    # ld_area sharded by query: the gathered hit list is the single-process hit list, on every rank
+    from ld_tools_amd import ld_area
+    n_snps, n_hap = 3000, 1008
+    whole = PackedPanel.from_codes(synth.synth_codes_device(n_snps, n_hap, seed=8, miss=0.002, device=dev))
+    rng = np.random.RandomState(3)
+    pos = np.cumsum(rng.choice([0, 1, 40, 2500], size=n_snps, p=[0.05, 0.35, 0.4, 0.2])) + 1
+    for queries, flank, measure, thres in [(None, 20000, "r_square", 0.8), (list(range(0, n_snps, 5)), 100000, "d_prime", 1.0),
+                                           ([17], 500, "r_square", 0.0), (None, 0, "r_square", 0.0)]:
+        want = ld_area(whole, pos, queries, flank, measure, thres)
+        got = ldist.ld_area_sharded(whole, pos, queries, flank, measure, thres)
+        assert torch.equal(got.query, want.query) and torch.equal(got.oppos, want.oppos), "sharded ld_area rows"
+        assert torch.equal(got.ld32.view(torch.int32), want.ld32.view(torch.int32)), "sharded ld_area values"
+        assert got.n_pairs == want.n_pairs, "sharded ld_area pair count"
+        own = ldist.ld_area_sharded(whole, pos, queries, flank, measure, thres, gather=False)
+        n_own = torch.tensor([len(own)], dtype=torch.int64)
+        dist.all_reduce(n_own)
+        assert int(n_own) == len(want)
     torch.cuda.synchronize()
     dist.barrier()
     if rank == 0:

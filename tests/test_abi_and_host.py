@@ -127,6 +127,26 @@ def test_slab_partition():
         assert all(x == big for x in slabs[:k]) and all(x == 0 for x in slabs[k + 1:])
 
 
+def test_query_partition_tiles_the_query_list_and_balances_pairs():
+    from ld_tools_amd import dist
+
+    rng = np.random.RandomState(9)
+    pos = np.cumsum(rng.choice([0, 1, 10, 900], size=5000, p=[0.05, 0.45, 0.4, 0.1])) + 1
+    for queries, flank, world in [(None, 5000, 8), (None, 0, 3), (list(range(0, 5000, 7)), 20000, 4), ([4, 2, 4999], 50, 8),
+                                  ([], 50, 2), (None, 10 ** 9, 5)]:
+        parts = dist.query_partition(pos, queries, flank, world)
+        nq = 5000 if queries is None else len(queries)
+        assert len(parts) == world and parts[0][0] == 0 and parts[-1][1] == nq
+        assert all(e0 == b1 for (_, e0), (b1, _) in zip(parts, parts[1:])) and all(b <= e for b, e in parts)
+        if nq >= 100 * world:
+            q = np.arange(5000) if queries is None else np.sort(np.array(queries))
+            lo = np.searchsorted(pos, np.maximum(pos[q] - flank, 0), side="right")
+            hi = np.searchsorted(pos, pos[q] + flank, side="right")
+            cost = (hi - lo) + 1
+            share = [int(cost[b:e].sum()) for b, e in parts]
+            assert max(share) <= 1.1 * sum(share) / world + int(cost.max())
+
+
 def test_synth_thresholds_and_positions():
     from ld_tools_amd import synth
 
