@@ -166,8 +166,16 @@ struct AreaArgs {
 };
 constexpr uint32_t kHitBatch = 256;   // hit slots a wave reserves per atomic (as in ldx_area.hip)
 
+// tuning build -DLDX_MM1: every ticket half-height (32-row accumulator tiles only), three workgroups per CU
+#ifdef LDX_MM1
+constexpr int kWgPerCu = 3;
+constexpr uint32_t kStatRows = 32;
+#else
+constexpr int kWgPerCu = 2;
+constexpr uint32_t kStatRows = kRows64;
+#endif
 template <bool kRaw, bool kN11, bool kArea = false>
-__global__ void __launch_bounds__(kMfmaThreads, 2)
+__global__ void __launch_bounds__(kMfmaThreads, kArea ? 2 : kWgPerCu)
 triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ fa, const double *__restrict__ fr,
                      const double *__restrict__ q, uint32_t n_snps, uint32_t n_slabs, uint32_t nchunks, double n,
                      double rn, uint64_t u_begin, uint64_t u_end, ldx_ld32 *__restrict__ out, ldx_ld64 *__restrict__ raw,
@@ -205,7 +213,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
     const uint32_t sel0 = half ? 0x02020202u : 0x00000000u;   // v_perm selectors: this lane's two bytes of an A word
     const uint32_t sel1 = half ? 0x03030303u : 0x01010101u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    double *rstat = cstat + kSlab * kStat + wave * (kRows64 * kStat);   // [64][kStat], private to the wave
+    double *rstat = cstat + kSlab * kStat + wave * ((kArea ? kRows64 : kStatRows) * kStat);   // [64][kStat], private to the wave
     const FastConst fk = fast_const(n, 8.0);
     // In-kernel stamps (tuning builds, env LDX_STAMPS=file): per wave {HW_ID | XCC_ID << 32, realtime, passes}
     // and per pass {start, prologue done, K loop done, epilogue done} in shader cycles; written to a buffer nothing else reads.
@@ -237,7 +245,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
     // do not run at the same speed: two that share a CU and fall into step (K loop beside K loop, epilogue
     // beside epilogue) take ~1.5x as long per pass as two in antiphase, and with an equal static share the
     // slowest pair set the kernel time (max wave lifetime 826k cycles against a median of 533k at 10k SNPs).
-    uint32_t *tickets = reinterpret_cast<uint32_t *>(cstat + kSlab * kStat + kMfmaWaves * (kRows64 * kStat));   // [2]
+    uint32_t *tickets = reinterpret_cast<uint32_t *>(cstat + kSlab * kStat + kMfmaWaves * ((kArea ? kRows64 : kStatRows) * kStat));   // [2]
     uint32_t *cols_odd = tickets + 2;   // [2]: per wave of the column stagers, != 0 if one of its columns is not "ordinary"
     auto draw = [&]() { return atomicAdd(&sched[0], 1u); };
     uint32_t parity = 0;
@@ -401,13 +409,15 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                     dst[1] = d2{c.rr, c.rq};
                     if (kArea) dst[2] = j < n_snps ? d2{(double)aa.pos[j], (double)aa.is_query[j]} : d2{0.0, 0.0};
                 }
-                const uint32_t i = row0 + lane;
+                const uint32_t i = row0 + (MM == 1 ? l32 : lane);   // a half-height unit has 32 rows: stay inside the padded vectors
                 const FastRow r = fast_row(fa[i], fr[i], n);
                 rows_ordinary = __all(fast_ordinary(fa[i], fr[i], n));
                 typedef double d2 __attribute__((ext_vector_type(2)));
-                d2 *dst = reinterpret_cast<d2 *>(rstat + lane * kStat);
-                dst[0] = d2{r.a_s, r.ra};
-                dst[1] = d2{r.rr, r.rq_s};
+                d2 *dst = reinterpret_cast<d2 *>(rstat + (lane < (kArea ? kRows64 : kStatRows) ? lane : 0u) * kStat);
+                if (lane < (kArea ? kRows64 : kStatRows)) {
+                    dst[0] = d2{r.a_s, r.ra};
+                    dst[1] = d2{r.rr, r.rq_s};
+                }
                 if (kArea) dst[2] = i < n_snps ? d2{(double)aa.pos[i], (double)aa.is_query[i]} : d2{0.0, 0.0};
             }
             __syncthreads();
@@ -524,9 +534,10 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 }
             }
             if (kRaw) {   // one coalesced load per statistic for the unit's 64 rows, handed out by shuffles below
-                sfa = fa[row0 + lane];
-                sfr = fr[row0 + lane];
-                sq = q[row0 + lane];
+                const uint32_t il = row0 + (MM == 1 ? l32 : lane);
+                sfa = fa[il];
+                sfr = fr[il];
+                sq = q[il];
             }
             // Two variants of the loop, chosen per wave and pass: the general one, and a "clean" one for units that
             // lie wholly below the diagonal, inside the panel and inside [u_begin, u_end), whose 64 rows and 128
@@ -796,8 +807,12 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
         if constexpr (kArea) {
             pass_body(std::integral_constant<int, 2>{});
         } else {
+#ifdef LDX_MM1
+            pass_body(std::integral_constant<int, 1>{});
+#else
             if (short_pass) pass_body(std::integral_constant<int, 1>{});
             else pass_body(std::integral_constant<int, 2>{});
+#endif
         }
     }
     if (kArea)   // the unused slots of this wave's last batch
@@ -844,7 +859,7 @@ static int launch_mfma(const void *alt, const double *fa, const double *fr, cons
                        uint32_t *out_n11, hipStream_t s)
 {
     const uint32_t nch = n_chunks(n_hap);
-    const size_t lds = 2u * kBBuf + (kSlab + kMfmaWaves * kRows64) * kStat * sizeof(double) + 32u;
+    const size_t lds = 2u * kBBuf + (kSlab + kMfmaWaves * kStatRows) * kStat * sizeof(double) + 32u;
     int dev = 0, cus = 256;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
@@ -868,13 +883,16 @@ static int launch_mfma(const void *alt, const double *fa, const double *fr, cons
     const uint32_t p_end = mfma_pass_base(t1, ns) + (uint32_t)((v_end - base64(t1) + kMfmaWaves - 1u) / kMfmaWaves);
     // The last passes go out as two half-height tickets each (32-row tiles: ~0.55 of a pass time for half the work),
     // so that the launch does not end with whole passes on a few workgroups while the rest of the chip idles.
-    const uint64_t slots = (uint64_t)cus * (8u / kMfmaWaves);   // persistent: 8 waves per CU = two workgroups
+    const uint64_t slots = (uint64_t)cus * kWgPerCu;   // persistent: two workgroups (8 waves) per CU
     const uint32_t n_pass = p_end - p_begin;
     // Measured at 10 000 x 5008 (1580 passes on 512 workgroups): 128 halved passes -3 %, 256..384 -1 %, all +13 %.
     // A launch of at most half a round (tiny panels) halves every pass: -20 % at 1000-2000 SNPs.
     uint32_t n_short = 2ull * n_pass <= slots ? n_pass : (n_pass > slots ? (uint32_t)(slots / 4u) : 0u);
     if (const char *env = getenv("LDX_SHORT"))   // tuning / tests: force the number of halved passes
         n_short = (uint32_t)atoi(env) < n_pass ? (uint32_t)atoi(env) : n_pass;
+#ifdef LDX_MM1
+    n_short = n_pass;
+#endif
     uint64_t grid = slots;
     if (grid > (uint64_t)n_pass + n_short) grid = (uint64_t)n_pass + n_short;
     if (grid < 1) grid = 1;
