@@ -110,6 +110,11 @@ __device__ __forceinline__ v4i expand16_a(uint32_t word, uint32_t sel0, uint32_t
 #else
 #define EXPAND_B(x) expand16(x)
 #endif
+#ifdef LDX_AB_NOBWRITE   // no expansion and no LDS write of the j-tile image (what a pre-expanded, DMA-fed image would save)
+#define BWRITE(dst, x) asm volatile("" : : "v"(x))
+#else
+#define BWRITE(dst, x) dst = EXPAND_B(x)
+#endif
 
 // In-chunk stamps (build with -DLDX_CHUNK_STAMPS on top of -DLDX_TUNING): s_memtime at six points of ONE chunk
 // (index LDX_CHUNK_STAMPS) of a wave's second pass, kept in SGPRs and written after the K loop.  Issued by
@@ -454,7 +459,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 /* step 0: MFMAs of (c,0); prepare (c,1); quarter 1 of this thread's share of B chunk c+1 */      \
                 read_bf(bf1, rd, 1);                                                                               \
                 _Pragma("unroll") for (int m = 0; m < MM; ++m) af1[m] = EXPAND_A(ar[CUR][m].y);               \
-                bdst[1] = EXPAND_B(br[NXT].x >> 16);                                                               \
+                BWRITE(bdst[1], br[NXT].x >> 16);                                                                  \
                 mma8(af0, bf0);                                                                                    \
                 interleave();                                                                                      \
                 __builtin_amdgcn_sched_barrier(0);                                                                 \
@@ -462,7 +467,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 /* step 1: MFMAs of (c,1); prepare (c,2); quarter 2 of the B share */                             \
                 read_bf(bf0, rd, 2);                                                                               \
                 _Pragma("unroll") for (int m = 0; m < MM; ++m) af0[m] = EXPAND_A(ar[CUR][m].z);               \
-                bdst[2] = EXPAND_B(br[NXT].y);                                                                     \
+                BWRITE(bdst[2], br[NXT].y);                                                                        \
                 mma8(af1, bf1);                                                                                    \
                 interleave();                                                                                      \
                 __builtin_amdgcn_sched_barrier(0);                                                                 \
@@ -470,7 +475,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 /* step 2: MFMAs of (c,2); prepare (c,3); quarter 3 of the B share */                             \
                 read_bf(bf1, rd, 3);                                                                               \
                 _Pragma("unroll") for (int m = 0; m < MM; ++m) af1[m] = EXPAND_A(ar[CUR][m].w);               \
-                bdst[3] = EXPAND_B(br[NXT].y >> 16);                                                               \
+                BWRITE(bdst[3], br[NXT].y >> 16);                                                                  \
                 mma8(af0, bf0);                                                                                    \
                 interleave();                                                                                      \
                 __builtin_amdgcn_sched_barrier(0);                                                                 \
@@ -485,7 +490,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 asm volatile("" : "+v"(br[FAR]));                                                                  \
                 read_bf(bf0, wr, 0);                                                                               \
                 _Pragma("unroll") for (int m = 0; m < MM; ++m) af0[m] = EXPAND_A(ar[NXT][m].x);               \
-                *reinterpret_cast<v4i *>(bexp + (c_ & 1u) * kBBuf + b_off) = EXPAND_B(br[FAR].x);                  \
+                BWRITE(*reinterpret_cast<v4i *>(bexp + (c_ & 1u) * kBBuf + b_off), br[FAR].x);                  \
                 mma8(af1, bf1);                                                                                    \
                 interleave();                                                                                      \
                 __builtin_amdgcn_sched_barrier(0);                                                                 \

@@ -2,6 +2,8 @@
 # A/B timing of tuning builds: for each library in $LIBS (paths under ld_tools_amd/), parity subset then timings
 set -u
 mkdir -p gpurun_out
+# a fresh box pages the image in on the first import (minutes): do that once, outside the timed steps' limits
+timeout -k 10 600 python -c "import torch; print('torch', torch.__version__, torch.cuda.is_available())" 2>&1 | tail -1
 for lib in ${LIBS:-libldx.so}; do
   echo "== $lib"
   export LDX_LIB=$PWD/ld_tools_amd/$lib
@@ -11,7 +13,7 @@ for lib in ${LIBS:-libldx.so}; do
     if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then exit $rc; fi
   fi
   for cfg in "10000 5008 mfma 30" "40000 5008 mfma 3" "50000 1008 mfma 3"; do
-    timeout -k 10 200 python tools/gpu_tri.py $cfg 2>&1 | grep -v amdgpu.ids; rc=${PIPESTATUS[0]}
+    timeout -k 10 300 python tools/gpu_tri.py $cfg 2>&1 | grep -v amdgpu.ids; rc=${PIPESTATUS[0]}
     if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then exit $rc; fi
   done
 done
