@@ -12,6 +12,11 @@ the pairs per GPU constant (weak scaling): S = 10 000 * sqrt(N) SNPs rounded up 
 row-block shards packed per rank, exchanged by all-gather, unit list split evenly (ld_tools_amd/dist.py).
 --snps overrides S (e.g. --snps 100000 for configs[3]).
 
+Timing: W warm-up steps, then --settle-steps more untimed steps (the shader clock needs tens of ms of load to
+settle; reported as config.settle_steps), then EXACTLY K steps between barrier + synchronize on both sides, max
+over ranks.  The K steps are replayed as one HIP graph (eager with --no-graph); the output is NaN-filled before the
+timed region and compared bit for bit with a separately computed result after it.
+
 Prints ONE JSON line on rank 0 (see the driver contract): whole-job pairs/s, ms per step, the roofline
 object of the dominant kernel (HIP events on the launch stream, live) and, at N = 1, the CPU baseline
 (the pure-Python restatement of the reference's list/zip/count algorithm, 1 core, bounded sample).
@@ -46,6 +51,9 @@ def parse():
     ap.add_argument("--force-dist", action="store_true", help="run the sharded path (process group + all-gather) even at world 1")
     ap.add_argument("--cpu-sample-snps", type=int, default=320)
     ap.add_argument("--no-graph", action="store_true", help="launch the steps eagerly instead of replaying a HIP graph")
+    ap.add_argument("--settle-steps", type=int, default=600,
+                    help="untimed steps run right before the timed region, on top of --warmup, so that it starts at "
+                         "sustained clocks (the shader clock needs tens of ms of load to settle; 0 = off)")
     ap.add_argument("--path", default="auto", choices=("auto", "mfma", "popcount"),
                     help="kernel behind ld_triangle (auto = the int8 MFMA kernel; results are identical)")
     return ap.parse_args()
@@ -183,6 +191,19 @@ def main():
             print(f"[bench] HIP graph capture unavailable ({type(exc).__name__}: {exc}); eager launches", file=sys.stderr)
             graph = None
             torch.cuda.synchronize()
+    # Clock settling (untimed, reported in config): a 20-step timed region is 5 ms, far shorter than the tens of ms the
+    # shader clock takes to settle under load, and would read 15 % slow whatever the launch method.
+    # A fixed step count, not a time, so that every rank issues the same collectives.
+    settle_done = 0
+    if args.settle_steps > 0:
+        if graph is not None:
+            for _ in range((args.settle_steps + args.steps - 1) // args.steps):
+                graph.replay()
+                settle_done += args.steps
+        else:
+            for _ in range(args.settle_steps):
+                step()
+                settle_done += 1
     if out is not None:
         out.ld32.fill_(float("nan"))       # the timed steps must produce every result again (checked below)
     fence()
@@ -259,6 +280,7 @@ def main():
                    "pairs_per_step": n_pairs, "output": "8 B/pair (f32 r2, f32 D', rounded to 4 decimals) in HBM",
                    "kernel_path": "int8 MFMA counts + f64 epilogue" if mfma else "AND+popcount counts + f64 epilogue",
                    "launch": "HIP graph of the K steps, output verified after the timed region" if graph is not None else "eager",
+                   "settle_steps": settle_done,   # untimed, beyond --warmup: the timed region starts at sustained clocks
                    "sharding": "none" if world == 1 else f"row-block shards, all-gather, pass list / {world}"},
         "roofline": roofline,
         "roofline_hbm": hbm,      # the metric's "% HBM roofline": output bytes + one read of the packed plane

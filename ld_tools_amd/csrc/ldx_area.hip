@@ -277,9 +277,7 @@ extern "C" int ldx_area_dev(const void *alt, const double *fa, const double *fr,
     LDX_HIP(hipGetLastError());
     const size_t lds = (size_t)nch * kSlab * 16u;
     LDX_HIP(hipFuncSetAttribute((const void *)area_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int dev = 0, cus = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    const int cus = device_cus();
     area_scan_kernel<<<cus, kThreads, lds, s>>>((const uint4 *)alt, w.qalt, fa, fr, positions, w.qpos, w.qrow, w.qfa,
                                                 w.qfr, w.qq, w.g_begin, w.unit_base, n_snps, T, nch, (double)n_hap,
                                                 flank, measure, thres_to_k(thres), hits, hit_cap,

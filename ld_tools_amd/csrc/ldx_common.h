@@ -318,4 +318,18 @@ __device__ __forceinline__ void ld_multi_fast2(const int (&cnt_scaled)[W], const
 }
 #undef LDX_STAGE
 
+// Compute units of the current device, cached per device ordinal: hipGetDeviceProperties costs tens of
+// microseconds per call, which an eager launch of a 0.25 ms kernel would feel.
+inline int device_cus()
+{
+    static int cached[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] > 0) return cached[dev];
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 256;
+    cached[dev] = cus;   // a race writes the same value twice
+    return cus;
+}
+
 }  // namespace ldx

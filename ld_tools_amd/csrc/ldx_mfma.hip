@@ -865,11 +865,7 @@ static int launch_mfma(const void *alt, const double *fa, const double *fr, cons
 {
     const uint32_t nch = n_chunks(n_hap);
     const size_t lds = 2u * kBBuf + (kSlab + kMfmaWaves * kStatRows) * kStat * sizeof(double) + 32u;
-    int dev = 0, cus = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-        prop.multiProcessorCount > 0)
-        cus = prop.multiProcessorCount;
+    const int cus = device_cus();
     // the range of passes that intersect [unit_begin, unit_end)
     const uint32_t ns = n_slabs(n_snps);
     const uint64_t G64 = (uint64_t)ns * 2u;
@@ -1023,11 +1019,7 @@ int area_mfma(const void *alt, const double *fa, const double *fr, const double 
     area_band_plan_kernel<<<1, 1024, 0, s>>>(positions, n_snps, T, flank, g_end, pass_base);
     LDX_HIP(hipGetLastError());
     const size_t lds = 2u * kBBuf + (kSlab + kMfmaWaves * kRows64) * kStat * sizeof(double) + 32u;
-    int dev = 0, cus = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-        prop.multiProcessorCount > 0)
-        cus = prop.multiProcessorCount;
+    const int cus = device_cus();
     uint32_t *sched = nullptr;
     if (int rc = acquire_sched(s, &sched)) return rc;
     AreaArgs aa;

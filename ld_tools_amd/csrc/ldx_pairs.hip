@@ -257,15 +257,7 @@ static int ensure_lds(const void *kernel, size_t bytes)
     return LDX_OK;
 }
 
-static int num_cus()
-{
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-        prop.multiProcessorCount > 0)
-        return prop.multiProcessorCount;
-    return 256;
-}
+static int num_cus() { return device_cus(); }
 
 template <bool kRaw, bool kN11>
 static int launch_triangle(const void *alt, const double *fa, const double *fr, const double *q, uint32_t n_snps,
