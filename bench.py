@@ -51,6 +51,10 @@ def parse():
     ap.add_argument("--force-dist", action="store_true", help="run the sharded path (process group + all-gather) even at world 1")
     ap.add_argument("--cpu-sample-snps", type=int, default=320)
     ap.add_argument("--no-graph", action="store_true", help="launch the steps eagerly instead of replaying a HIP graph")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N > 1: finish each step's all-gather before its kernel instead of overlapping it with the "
+                         "previous step's kernel")
+    ap.add_argument("--overlap", action="store_true", help="use the overlapped exchange even in a one-rank group (rehearsals)")
     ap.add_argument("--settle-steps", type=int, default=600,
                     help="untimed steps run right before the timed region, on top of --warmup, so that it starts at "
                          "sustained clocks (the shader clock needs tens of ms of load to settle; 0 = off)")
@@ -155,23 +159,39 @@ def main():
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
-    def step(k=None):
+    # N > 1: every step exchanges the packed shards (ONE RCCL all-gather) and runs this rank's share of the kernel.
+    # The exchange of step k + 1 is issued before the kernel of step k and finished after it (double-buffered
+    # panels, dist.PanelPipeline): RCCL works on its own stream, so the all-gather over xGMI rides under the
+    # kernel instead of in front of it.  run_steps(K) = K exchanges + K kernels, nothing left in flight.
+    overlap = use_dist and not args.no_overlap and (world > 1 or args.overlap)   # a one-rank group has nothing to hide
+    pipe = ldist.PanelPipeline(n_snps, n_hap, dev) if overlap else None
+
+    def step(k=None, first=True, last=True):
         nonlocal out, panel
-        if use_dist:
-            panel = ldist.all_gather_panel(local, n_snps, n_hap, out=panel)   # the exchange step: ONE RCCL all-gather
+        if pipe is not None:
+            if first:
+                pipe.start(local)
+            panel = pipe.finish()
+            if not last:
+                pipe.start(local)
+        elif use_dist:
+            panel = ldist.all_gather_panel(local, n_snps, n_hap, out=panel)
         if k is not None:
             ev0[k].record()
         out = ld_triangle(panel, unit_range=(u0, u1), out=out)
         if k is not None:
             ev1[k].record()
 
+    def run_steps(count, timed=False):
+        for k in range(count):
+            step(k if timed else None, first=(k == 0), last=(k == count - 1))
+
     def fence():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup)
     fence()
     # The K steps are K back-to-back launches of a 0.25 ms kernel (plus, for N > 1, the exchange's all-gather and a
     # handful of small copies): a launch-bound inner loop, captured once into a HIP graph and replayed inside the
@@ -182,8 +202,7 @@ def main():
         try:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                for _ in range(args.steps):
-                    step()
+                run_steps(args.steps)
             g.replay()                      # one untimed replay (also proves the graph runs)
             torch.cuda.synchronize()
             graph = g
@@ -201,9 +220,8 @@ def main():
                 graph.replay()
                 settle_done += args.steps
         else:
-            for _ in range(args.settle_steps):
-                step()
-                settle_done += 1
+            run_steps(args.settle_steps)
+            settle_done = args.settle_steps
     if out is not None:
         out.ld32.fill_(float("nan"))       # the timed steps must produce every result again (checked below)
     fence()
@@ -213,8 +231,7 @@ def main():
         graph.replay()
         ev1[0].record()
     else:
-        for k in range(args.steps):
-            step(k)
+        run_steps(args.steps, timed=True)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -281,7 +298,9 @@ def main():
                    "kernel_path": "int8 MFMA counts + f64 epilogue" if mfma else "AND+popcount counts + f64 epilogue",
                    "launch": "HIP graph of the K steps, output verified after the timed region" if graph is not None else "eager",
                    "settle_steps": settle_done,   # untimed, beyond --warmup: the timed region starts at sustained clocks
-                   "sharding": "none" if world == 1 else f"row-block shards, all-gather, pass list / {world}"},
+                   "sharding": "none" if world == 1 else f"row-block shards, all-gather, pass list / {world}",
+                   "exchange": ("none" if not use_dist else "per step, overlapped with the previous step's kernel"
+                                if pipe is not None else "per step, before the kernel")},
         "roofline": roofline,
         "roofline_hbm": hbm,      # the metric's "% HBM roofline": output bytes + one read of the packed plane
     }

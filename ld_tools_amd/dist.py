@@ -106,41 +106,53 @@ def gather_shards(dst, src, sizes, group=None):
         off += n
 
 
-def fused_gather(full, local, slabs, slab_bytes: int, group=None, stage=None):
-    """ONE all-gather for a whole panel shard.  ``full`` / ``local`` are dicts of 1-D tensors (any device /
-    backend): 'alt' (uint8, whole slab images), 'acnt', 'rcnt' (int32, 128 per slab) and optionally 'ref'; ``local``
-    holds this rank's slabs (or is None), ``full`` receives all ranks' in rank order; ``slabs[r]`` = slabs of rank r.
+def _gather_layout(slabs, slab_bytes: int, with_ref: bool):
+    big = max(slabs)
+    cnt_bytes = SLAB * 4
+    per_slab = slab_bytes * (2 if with_ref else 1) + 2 * cnt_bytes
+    o_acnt = big * slab_bytes
+    o_rcnt = o_acnt + big * cnt_bytes
+    o_ref = o_rcnt + big * cnt_bytes
+    return big, cnt_bytes, per_slab, o_acnt, o_rcnt, o_ref
 
-    Every rank contributes a single byte shard [ALT: big slabs | acnt | rcnt (| REF: big slabs)], big = the largest
-    rank's slab count; the pieces are then copied to their places (strided copies when the shards are equal).
-    Returns the (send, recv) staging buffers for re-use.
-    """
+
+def fused_gather_start(local, slabs, slab_bytes: int, dev, group=None, stage=None, with_ref: bool = False,
+                       async_op: bool = False):
+    """First half of fused_gather: fill this rank's byte shard and issue the ONE all-gather.  Returns
+    (stage, work): the (send, recv) staging buffers and, with ``async_op``, the collective's Work handle (else None:
+    the call has already made the current stream wait for the collective)."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    with_ref = "ref" in full
-    big = max(slabs)
-    cnt_bytes = SLAB * 4
-    per_slab = slab_bytes * (2 if with_ref else 1) + 2 * cnt_bytes
-    dev = full["alt"].device
+    big, cnt_bytes, per_slab, o_acnt, o_rcnt, o_ref = _gather_layout(slabs, slab_bytes, with_ref)
     if stage is None or stage[0].numel() != big * per_slab or stage[1].numel() != world * big * per_slab:
         stage = (torch.zeros(big * per_slab, dtype=torch.uint8, device=dev),
                  torch.empty(world * big * per_slab, dtype=torch.uint8, device=dev))
     send, recv = stage
     mine = slabs[rank]
-    o_acnt = big * slab_bytes
-    o_rcnt = o_acnt + big * cnt_bytes
-    o_ref = o_rcnt + big * cnt_bytes
     if local is not None and mine:
         send[: mine * slab_bytes] = local["alt"][: mine * slab_bytes]
         send[o_acnt: o_acnt + mine * cnt_bytes] = local["acnt"][: mine * SLAB].view(torch.uint8)
         send[o_rcnt: o_rcnt + mine * cnt_bytes] = local["rcnt"][: mine * SLAB].view(torch.uint8)
         if with_ref:
             send[o_ref: o_ref + mine * slab_bytes] = local["ref"][: mine * slab_bytes]
-    dist.all_gather_into_tensor(recv, send, group=group)
-    shard = recv.view(world, big * per_slab)
+    work = dist.all_gather_into_tensor(recv, send, group=group, async_op=async_op)
+    return stage, (work if async_op else None)
+
+
+def fused_gather_finish(full, stage, slabs, slab_bytes: int, work=None):
+    """Second half: wait for the collective (if it was issued asynchronously) and copy the pieces of every rank's
+    shard to their places in ``full`` (strided copies when the shards are equal)."""
+    import torch
+
+    if work is not None:
+        work.wait()                                # the current stream waits; the host does not
+    with_ref = "ref" in full
+    world = len(slabs)
+    big, cnt_bytes, per_slab, o_acnt, o_rcnt, o_ref = _gather_layout(slabs, slab_bytes, with_ref)
+    shard = stage[1].view(world, big * per_slab)
     acnt8, rcnt8 = full["acnt"].view(torch.uint8), full["rcnt"].view(torch.uint8)
     if len(set(slabs)) == 1:                       # equal shards: one strided copy per piece
         full["alt"].view(world, big * slab_bytes).copy_(shard[:, :o_acnt])
@@ -165,6 +177,19 @@ def fused_gather(full, local, slabs, slab_bytes: int, group=None, stage=None):
             if with_ref:
                 full["ref"][off * slab_bytes: (off + n) * slab_bytes] = shard[r, o_ref: o_ref + n * slab_bytes]
             off += n
+
+
+def fused_gather(full, local, slabs, slab_bytes: int, group=None, stage=None):
+    """ONE all-gather for a whole panel shard.  ``full`` / ``local`` are dicts of 1-D tensors (any device /
+    backend): 'alt' (uint8, whole slab images), 'acnt', 'rcnt' (int32, 128 per slab) and optionally 'ref'; ``local``
+    holds this rank's slabs (or is None), ``full`` receives all ranks' in rank order; ``slabs[r]`` = slabs of rank r.
+
+    Every rank contributes a single byte shard [ALT: big slabs | acnt | rcnt (| REF: big slabs)], big = the largest
+    rank's slab count; the pieces are then copied to their places (strided copies when the shards are equal).
+    Returns the (send, recv) staging buffers for re-use.
+    """
+    stage, _ = fused_gather_start(local, slabs, slab_bytes, full["alt"].device, group, stage, "ref" in full)
+    fused_gather_finish(full, stage, slabs, slab_bytes)
     return stage
 
 
@@ -197,6 +222,53 @@ def all_gather_panel(local, n_snps: int, n_hap: int, group=None, out=None, with_
     full._gather_stage = fused_gather(fd, ld, slabs, slab_bytes, group, getattr(full, "_gather_stage", None))
     full.refresh_stats()
     return full
+
+
+class PanelPipeline:
+    """Double-buffered exchange for a stream of batches: while the kernel of batch k runs, the all-gather of batch
+    k + 1 is in flight (RCCL runs collectives on its own stream; only the Work's wait() ties it back to the compute
+    stream).  Per batch:  ``start(local)`` fills the send shard and issues the all-gather asynchronously,
+    ``finish()`` -- one batch later -- makes the compute stream wait for it, places the pieces in the next of two
+    full panels and returns that panel.  At most one exchange is in flight; buffers alternate, so the panel a kernel
+    is still reading is never the one being filled."""
+
+    def __init__(self, n_snps: int, n_hap: int, device, group=None):
+        import torch.distributed as dist
+
+        from .panel import PackedPanel
+
+        self.n_snps, self.n_hap, self.group = n_snps, n_hap, group
+        self.world = dist.get_world_size(group)
+        parts = slab_partition(n_snps, self.world)
+        self.slabs = [(e - b + SLAB - 1) // SLAB for (b, e) in parts]
+        self.slab_bytes = ((n_hap + 127) // 128) * SLAB * 16
+        self.panels = [PackedPanel.empty(n_snps, n_hap, device) for _ in range(2)]
+        self.stages = [None, None]
+        self.device = device
+        self.issued = 0          # exchanges started
+        self.done = 0            # exchanges finished
+        self.work = None
+
+    def start(self, local) -> None:
+        if self.issued != self.done:
+            raise RuntimeError("PanelPipeline.start: the previous exchange has not been finished")
+        k = self.issued % 2
+        ld = None if local is None else {"alt": local.alt, "acnt": local.acnt, "rcnt": local.rcnt}
+        self.stages[k], self.work = fused_gather_start(ld, self.slabs, self.slab_bytes, self.device, self.group,
+                                                       self.stages[k], False, async_op=True)
+        self.issued += 1
+
+    def finish(self):
+        if self.issued != self.done + 1:
+            raise RuntimeError("PanelPipeline.finish: no exchange in flight")
+        k = self.done % 2
+        full = self.panels[k]
+        fused_gather_finish({"alt": full.alt, "acnt": full.acnt, "rcnt": full.rcnt}, self.stages[k], self.slabs,
+                            self.slab_bytes, self.work)
+        self.work = None
+        self.done += 1
+        full.refresh_stats()
+        return full
 
 
 # --------------------------------------------------------------------------- ld_area

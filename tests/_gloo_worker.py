@@ -68,6 +68,12 @@ def main():
             stage = None
             for _ in range(2):
                 stage = ldist.fused_gather(full, local, slabs, slab_bytes, stage=stage)
+            for piece in full.values():                # and once more through the asynchronous halves (PanelPipeline's calls)
+                piece.zero_()
+            stage, work = ldist.fused_gather_start(local, slabs, slab_bytes, torch.device("cpu"), None, stage, with_ref,
+                                                   async_op=True)
+            assert work is not None
+            ldist.fused_gather_finish(full, stage, slabs, slab_bytes, work)
             assert np.array_equal(full["alt"].numpy(), want), "fused gather: ALT plane"
             fa = np.zeros(npad_full, dtype=np.int32)
             fr_ = np.zeros(npad_full, dtype=np.int32)

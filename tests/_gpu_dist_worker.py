@@ -44,6 +44,22 @@ def main():
         assert torch.equal(part.n11, full.n11[u0 * UNIT_PAIRS: u1 * UNIT_PAIRS]), "shard counts"
         with_ref = ldist.all_gather_panel(local, n_snps, n_hap, with_ref=True)
         assert torch.equal(with_ref.ref, whole.ref), "gathered REF plane"
+        # the double-buffered pipeline: exchange of batch k + 1 in flight while batch k's kernel runs
+        pipe = ldist.PanelPipeline(n_snps, n_hap, dev)
+        pipe.start(local)
+        for k in range(4):
+            got = pipe.finish()
+            if k < 3:
+                pipe.start(local)
+            assert got is pipe.panels[k % 2]
+            r = ld_triangle(got, unit_range=(u0, u1))
+            assert torch.equal(got.alt, whole.alt) and torch.equal(got.acnt, whole.acnt) and torch.equal(got.q, whole.q)
+            assert torch.equal(r.ld32.view(torch.int32), part.ld32.view(torch.int32)), "pipelined shard results"
+        try:
+            pipe.finish()
+            raise AssertionError("finish without an exchange in flight must fail")
+        except RuntimeError:
+            pass
     # ld_area sharded by query: the gathered hit list is the single-process hit list, on every rank
     from ld_tools_amd import ld_area
     n_snps, n_hap = 3000, 1008
