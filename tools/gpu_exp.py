@@ -6,6 +6,7 @@
     python tools/gpu_exp.py tri100k    # configs[3] on one GPU: 100k x 5008 triangle
     python tools/gpu_exp.py eur        # configs[4] shape on the popcount path: 50k x 1008
     python tools/gpu_exp.py pack       # pack kernel bandwidth
+    python tools/gpu_exp.py small      # configs[0] and other driver-sized tables: codes on the host -> ld_two_dim on the host
 """
 import json
 import sys
@@ -40,6 +41,27 @@ def main():
         p = PackedPanel.from_codes(synth.synth_codes_device(n, h))
         ms = timed(lambda: pair_counts(p), reps=5)
         out.update(ms=ms, pairs=n * n, pairs_per_s=n * n / (ms * 1e-3), lane_ops_T=n * n * 314 / (ms * 1e-3) / 1e12)
+    elif what == "small":
+        import numpy as np
+
+        from ld_tools_amd.drivers.ingest import k_to_python
+        rows = []
+        for n in (64, 256, 1000, 2000):
+            codes = synth.synth_codes_host(n, 5008, seed=3)
+            def whole():                                          # drivers/triangle.py: triangle_matrix without the VCF reads
+                p = PackedPanel.from_codes(codes)                 # H2D + pack
+                dense = ld_triangle(p).dense("r_square", None).cpu().numpy()
+                flat = k_to_python(dense)
+                return [flat[r * n:(r + 1) * n] for r in range(n)]   # the reference's ld_two_dim
+            whole()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                whole()
+            wall = (time.perf_counter() - t0) / 3
+            p = PackedPanel.from_codes(codes)
+            ms = timed(lambda: ld_triangle(p), reps=20)
+            rows.append({"snps": n, "pairs": n * (n - 1) // 2, "kernel_ms": ms, "host_to_host_ms": wall * 1e3})
+        out["rows"] = rows
     elif what == "area":
         n, h = 100000, 5008
         p = PackedPanel.from_codes(synth.synth_codes_device(n, h))
