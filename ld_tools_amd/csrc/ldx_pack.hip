@@ -32,49 +32,71 @@ __device__ inline void codes16(uint4 v, uint32_t &alt, uint32_t &ref)
     }
 }
 
-// One wavefront per SNP row.  Lane l handles haplotypes [1024*s + 16*l, +16) of segment s: a
-// 16-byte coalesced load, 16 alt + 16 ref bits, stored as one uint16 into the tiled planes (8
-// lanes fill one 16-byte chunk).  Counts are reduced across the wave.
+// One workgroup per (slab, pair of chunks): 128 SNP rows x 256 haplotypes = 32 KiB of codes.  A thread owns 32
+// consecutive haplotypes of a row (two 16-byte loads; a wave covers 8 rows x 256 contiguous bytes) in four rows, all
+// eight loads issued before the first use; the 32 ALT / 32 REF bits go to LDS as one word each, and after one
+// barrier the workgroup writes the two chunk images of the slab -- 2 x 2 KiB per plane, contiguous in the tiled
+// layout -- as one 16-byte store per thread and plane.  Every element of the planes is written (pad rows and pad
+// haplotypes as zero bits), so the planes need no memset; the per-SNP counts are accumulated with integer atomics
+// (one per row, plane and workgroup) into vectors the caller has zeroed.
 __global__ void __launch_bounds__(256) pack_codes_kernel(const int8_t *__restrict__ codes, uint32_t n_snps,
-                                                         uint32_t n_hap, size_t ld, uint16_t *__restrict__ alt,
-                                                         uint16_t *__restrict__ ref, uint32_t *__restrict__ acnt,
+                                                         uint32_t n_hap, size_t ld, uint4 *__restrict__ alt,
+                                                         uint4 *__restrict__ ref, uint32_t *__restrict__ acnt,
                                                          uint32_t *__restrict__ rcnt, uint32_t nchunks)
 {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t row = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (row >= n_snps) return;
-    const int8_t *g = codes + (size_t)row * ld;
-    const bool aligned = ((reinterpret_cast<uintptr_t>(g) & 15u) == 0);
-    const uint32_t slab = row / kSlab, rin = row % kSlab;
-    uint32_t ca = 0, cr = 0;
-    for (uint32_t h0 = lane * 16u; h0 < n_hap; h0 += 1024u) {
-        uint32_t a, r;
-        if (aligned && h0 + 16u <= n_hap) {
-            codes16(*reinterpret_cast<const uint4 *>(g + h0), a, r);
-        } else {
-            a = 0;
-            r = 0;
-            for (uint32_t k = 0; k < 16u && h0 + k < n_hap; ++k) {
-                const int8_t c = g[h0 + k];
+    __shared__ uint32_t la[2][kSlab][4], lr[2][kSlab][4];   // [chunk of the pair][row][32-haplotype word]
+    const uint32_t t = threadIdx.x, g = t & 7u, rbase = t >> 3;
+    const uint32_t slab = blockIdx.y, c0 = blockIdx.x * 2u;
+    const uint32_t h0 = c0 * 128u + g * 32u;
+    uint4 v[4][2];
+    bool fast[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const uint32_t row = slab * kSlab + it * 32u + rbase;
+        const int8_t *src = codes + (size_t)(row < n_snps ? row : 0u) * ld + h0;
+        fast[it] = row < n_snps && h0 + 32u <= n_hap && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0);
+        if (fast[it]) {
+            v[it][0] = reinterpret_cast<const uint4 *>(src)[0];
+            v[it][1] = reinterpret_cast<const uint4 *>(src)[1];
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const uint32_t rin = it * 32u + rbase, row = slab * kSlab + rin;
+        uint32_t a = 0, r = 0;
+        if (fast[it]) {
+            uint32_t a0, r0, a1, r1;
+            codes16(v[it][0], a0, r0);
+            codes16(v[it][1], a1, r1);
+            a = a0 | (a1 << 16);
+            r = r0 | (r1 << 16);
+        } else if (row < n_snps) {   // ragged end of the row or an unaligned row: byte by byte
+            const int8_t *src = codes + (size_t)row * ld;
+            for (uint32_t k = 0; k < 32u && h0 + k < n_hap; ++k) {
+                const int8_t c = src[h0 + k];
                 a |= (uint32_t)(c == 1) << k;
                 r |= (uint32_t)(c == 0) << k;
             }
         }
-        ca += __builtin_popcount(a);
-        cr += __builtin_popcount(r);
-        const uint32_t chunk = h0 >> 7, sub = (h0 >> 4) & 7u;   // 8 uint16 per 16-byte chunk
-        const size_t idx = (((size_t)slab * nchunks + chunk) * kSlab + rin) * 8u + sub;
-        alt[idx] = (uint16_t)a;
-        if (ref) ref[idx] = (uint16_t)r;
-    }
+        la[g >> 2][rin][g & 3u] = a;
+        lr[g >> 2][rin][g & 3u] = r;
+        uint32_t ca = __builtin_popcount(a), cr = __builtin_popcount(r);
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        ca += __shfl_xor(ca, off);
-        cr += __shfl_xor(cr, off);
+        for (int off = 4; off > 0; off >>= 1) {   // the 8 lanes of a row are adjacent
+            ca += __shfl_xor(ca, off);
+            cr += __shfl_xor(cr, off);
+        }
+        if (g == 0 && row < n_snps) {
+            if (ca) atomicAdd(&acnt[row], ca);
+            if (rcnt && cr) atomicAdd(&rcnt[row], cr);
+        }
     }
-    if (lane == 0) {
-        acnt[row] = ca;
-        if (rcnt) rcnt[row] = cr;
+    __syncthreads();
+    const uint32_t chunk = t >> 7, rin = t & 127u;
+    if (c0 + chunk < nchunks) {
+        const size_t idx = ((size_t)slab * nchunks + c0 + chunk) * kSlab + rin;
+        alt[idx] = *reinterpret_cast<const uint4 *>(&la[chunk][rin][0]);
+        if (ref) ref[idx] = *reinterpret_cast<const uint4 *>(&lr[chunk][rin][0]);
     }
 }
 
@@ -136,16 +158,12 @@ extern "C" int ldx_pack_codes_dev(const int8_t *codes, uint32_t n_snps, uint32_t
     LDX_REQUIRE((ref == nullptr) == (rcnt == nullptr), "ref and rcnt must be given together");
     LDX_REQUIRE(n_snps > 0 && n_hap > 0 && ld_codes >= n_hap, "bad shape");
     hipStream_t s = (hipStream_t)stream;
-    const size_t bytes = ldx_plane_bytes(n_snps, n_hap);
     const uint32_t npad = ldx_padded_snps(n_snps);
-    LDX_HIP(hipMemsetAsync(alt, 0, bytes, s));
-    LDX_HIP(hipMemsetAsync(acnt, 0, npad * sizeof(uint32_t), s));
-    if (ref) {
-        LDX_HIP(hipMemsetAsync(ref, 0, bytes, s));
-        LDX_HIP(hipMemsetAsync(rcnt, 0, npad * sizeof(uint32_t), s));
-    }
-    pack_codes_kernel<<<(n_snps + 3u) / 4u, 256, 0, s>>>(codes, n_snps, n_hap, ld_codes, (uint16_t *)alt,
-                                                        (uint16_t *)ref, acnt, rcnt, n_chunks(n_hap));
+    LDX_HIP(hipMemsetAsync(acnt, 0, npad * sizeof(uint32_t), s));   // the planes are written in full by the kernel
+    if (ref) LDX_HIP(hipMemsetAsync(rcnt, 0, npad * sizeof(uint32_t), s));
+    const uint32_t nch = n_chunks(n_hap);
+    pack_codes_kernel<<<dim3((nch + 1u) / 2u, n_slabs(n_snps)), 256, 0, s>>>(codes, n_snps, n_hap, ld_codes, (uint4 *)alt,
+                                                                             (uint4 *)ref, acnt, rcnt, nch);
     LDX_HIP(hipGetLastError());
     return LDX_OK;
 }
