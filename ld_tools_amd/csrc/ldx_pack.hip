@@ -6,30 +6,27 @@
 
 namespace ldx {
 
-// bit 7 of every byte of v that equals zero (exact per byte)
-__device__ inline uint32_t zero_bytes(uint32_t v)
-{
-    return ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v | 0x7F7F7F7Fu);
-}
-
-// gather bit 7 of the 4 bytes into bits 0..3
-__device__ inline uint32_t gather4(uint32_t f)
-{
-    f >>= 7;   // flags now at bits 0, 8, 16, 24
-    return (f | (f >> 7) | (f >> 14) | (f >> 21)) & 0xFu;
-}
-
-// 16 codes (one uint4 of int8) -> 16 alt bits (code == 1) and 16 ref bits (code == 0)
+// 16 codes (one uint4 of int8) -> 16 alt bits (code == 1) and 16 ref bits (code == 0).
+// Per 4-byte word, SWAR: bit 7 of a byte of `le1` is set iff the code is 0 or 1 (exact for every byte value: the
+// 7-bit add cannot carry out of its byte); the code's own bit 0, moved to bit 7, splits that into the ALT and REF
+// flags.  The four flag bytes of a word (0x80 or 0) are gathered by ONE v_dot4_u32_u8 against per-byte weights
+// 2^i (bits 0-3) or 2^(4+i) (bits 4-7): the sum is 128 x the 8-bit group of two words.
 __device__ inline void codes16(uint4 v, uint32_t &alt, uint32_t &ref)
 {
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-    alt = 0;
-    ref = 0;
+    uint32_t a2[2] = {0u, 0u}, r2[2] = {0u, 0u};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        alt |= gather4(zero_bytes(w[k] ^ 0x01010101u)) << (4 * k);
-        ref |= gather4(zero_bytes(w[k])) << (4 * k);
+        const uint32_t m = w[k] & 0xFEFEFEFEu;
+        const uint32_t t = ((m & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | m;   // bit 7: the code has a bit other than bit 0
+        const uint32_t le1 = ~t & 0x80808080u;
+        const uint32_t hi = w[k] << 7;                               // bit 7 of each byte: the code's bit 0
+        const uint32_t wt = (k & 1) ? 0x80402010u : 0x08040201u;
+        a2[k >> 1] = __builtin_amdgcn_udot4(le1 & hi, wt, a2[k >> 1], false);
+        r2[k >> 1] = __builtin_amdgcn_udot4(le1 & ~hi, wt, r2[k >> 1], false);
     }
+    alt = (a2[0] >> 7) | (a2[1] << 1);
+    ref = (r2[0] >> 7) | (r2[1] << 1);
 }
 
 // One workgroup per (slab, pair of chunks): 128 SNP rows x 256 haplotypes = 32 KiB of codes.  A thread owns 32
