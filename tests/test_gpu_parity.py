@@ -89,6 +89,32 @@ def test_pack_matches_oracle(gpu, name, panel_codes):
     assert np.array_equal(p.alt_freq4().cpu().numpy(), want_f4)
 
 
+@pytest.mark.parametrize("shape", [(130, 300), (257, 5008), (5, 31), (128, 256), (129, 257), (300, 10240)])
+def test_pack_every_byte_value_and_repack(gpu, shape):
+    """list.count semantics for ANY int8 code (calc_ld.py:37-40: only == 1 and == 0 count), on shapes either side of the
+    kernel's 128-row x 256-haplotype tiles; packing twice into the same panel gives the same planes and counts (the
+    counts are accumulated with atomics into vectors the call zeroes itself)."""
+    import torch
+
+    from ld_tools_amd import PackedPanel
+
+    n, h = shape
+    rng = np.random.RandomState(n * 7 + h)
+    codes = rng.randint(-128, 128, size=(n, h)).astype(np.int8)
+    codes[rng.random_sample((n, h)) < 0.6] = 1
+    codes[rng.random_sample((n, h)) < 0.3] = 0
+    p = PackedPanel.from_codes(codes)
+    alt, alt_all = untile(p.alt.cpu().numpy(), n, h)
+    ref, ref_all = untile(p.ref.cpu().numpy(), n, h)
+    assert np.array_equal(alt, codes == 1) and np.array_equal(ref, codes == 0)
+    assert alt_all.sum() == (codes == 1).sum() and ref_all.sum() == (codes == 0).sum()
+    assert np.array_equal(p.alt_counts(), (codes == 1).sum(axis=1)) and np.array_equal(p.ref_counts(), (codes == 0).sum(axis=1))
+    before = (p.alt.clone(), p.ref.clone(), p.acnt.clone(), p.rcnt.clone())
+    p.alt.fill_(255)                          # stale contents must not survive a re-pack
+    p.pack_from(torch.from_numpy(codes).to(gpu))
+    assert all(torch.equal(a, b) for a, b in zip(before, (p.alt, p.ref, p.acnt, p.rcnt)))
+
+
 def test_pack_unaligned_rows_and_tile_plane(gpu):
     import torch
 
