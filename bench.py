@@ -81,6 +81,25 @@ def cpu_baseline(codes_host, sample_snps):
            "sample": f"all {pairs} row>col pairs of the first {len(rows)} SNPs of the bench panel "
                      f"({codes_host.shape[1]} haplotypes), oracle/ld_oracle.py calc_ld_lists, {dt:.1f} s",
            "cpu": _cpu_model(), "host_cores": os.cpu_count()}
+    # the same sample over a process pool capped like the reference's (min(8, cores), ld_triangle.py:394-399); the
+    # workers are spawned (this process has initialised HIP and must not fork) and import the oracle only
+    try:
+        import multiprocessing as mp
+        nproc = min(8, os.cpu_count() or 1)
+        if nproc > 1:
+            n = len(rows)
+            cuts = [int(round(n * math.sqrt(k / nproc))) for k in range(nproc + 1)]    # equal pair counts per worker
+            with mp.get_context("spawn").Pool(nproc) as pool:          # every wait is bounded: an extra must not hang the bench
+                pool.starmap_async(orc.triangle_rows_lists, [(rows[:2], 0, 2)] * nproc).get(timeout=120)   # workers up
+                t0 = time.perf_counter()
+                done = sum(pool.starmap_async(orc.triangle_rows_lists,
+                                              [(rows, cuts[k], cuts[k + 1]) for k in range(nproc)]).get(timeout=180))
+                dtp = time.perf_counter() - t0
+            out["pool"] = {"value": done / dtp, "unit": "pairs/s", "cores": nproc,
+                           "sample": f"the same {done} pairs over multiprocessing.Pool({nproc}), spawn, {dtp:.1f} s "
+                                     "(argument pickling included)"}
+    except Exception as exc:   # noqa: BLE001  (a reported extra, never a reason to lose the bench line)
+        out["pool"] = {"error": f"{type(exc).__name__}: {exc}"}
     # the C restatement (AND + popcount + fp64 mirror), one thread, as the stronger CPU comparator
     n_c = min(codes_host.shape[0], 1536)
     p = c_oracle.Panel(codes_host[:n_c])

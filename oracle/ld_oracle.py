@@ -102,6 +102,18 @@ def calc_ld_lists(g1, g2):
     return ld_from_counts(*pair_counts_lists(g1, g2))
 
 
+def triangle_rows_lists(rows, i0: int, i1: int) -> int:
+    """calc_ld_lists for every pair (i, j), i0 <= i < i1, j < i -- one worker's share when the pair loop is spread
+    over a process pool the way the reference spreads input files (ld_triangle.py:394-409).  Returns the pair count."""
+    pairs = 0
+    for i in range(i0, i1):
+        gi = rows[i]
+        for j in range(i):
+            calc_ld_lists(gi, rows[j])
+            pairs += 1
+    return pairs
+
+
 def round4(x: float) -> float:
     """Exact emulation of Python's round(x, 4) for finite x >= 0, float ops only.
 
