@@ -58,7 +58,7 @@ def parse():
     ap.add_argument("--settle-steps", type=int, default=600,
                     help="untimed steps run right before the timed region, on top of --warmup, so that it starts at "
                          "sustained clocks (the shader clock needs tens of ms of load to settle; 0 = off)")
-    ap.add_argument("--path", default="auto", choices=("auto", "mfma", "popcount"),
+    ap.add_argument("--path", default="auto", choices=("auto", "fp4", "mfma", "popcount"),
                     help="kernel behind ld_triangle (auto = the int8 MFMA kernel; results are identical)")
     return ap.parse_args()
 

@@ -18,7 +18,8 @@
  *
  * Packed panel layout in HBM ("tiled plane")
  *   A plane holds one bit per (SNP, haplotype).  Rows are grouped into slabs of LDX_SLAB_ROWS
- *   SNPs; the haplotype axis is cut into chunks of 128 haplotypes (16 bytes).  Element
+ *   SNPs; the haplotype axis is cut into chunks of 128 haplotypes (16 bytes), allocated in pairs
+ *   (n_chunks = 2 * ceil(n_hap / 256): the matrix kernel consumes two chunks per K-block).  Element
  *   (slab s, chunk c, row r) is the 16-byte group at byte offset
  *       ((s * n_chunks + c) * LDX_SLAB_ROWS + r) * 16,
  *   bit (h % 128) of it (little-endian, 32-bit words) being haplotype h = 128*c + (h % 128) of
@@ -82,7 +83,7 @@ int ldx_device_arch(int device, char *buf, size_t buflen);   /* e.g. "gfx950" */
 
 /* ---- geometry helpers (pure arithmetic, usable without a GPU) ------------------------- */
 uint32_t ldx_n_slabs(uint32_t n_snps);                     /* ceil(n_snps / 128) */
-uint32_t ldx_n_chunks(uint32_t n_hap);                     /* ceil(n_hap / 128) */
+uint32_t ldx_n_chunks(uint32_t n_hap);                     /* 2 * ceil(n_hap / 256): chunks come in pairs */
 size_t ldx_plane_bytes(uint32_t n_snps, uint32_t n_hap);   /* bytes of one tiled plane */
 uint32_t ldx_padded_snps(uint32_t n_snps);                 /* n_slabs * 128 */
 /* Triangle work units.  Unit u of the strict lower triangle pairs the 8 rows of group g with the
@@ -131,14 +132,22 @@ int ldx_ld_from_counts_dev(uint32_t n, size_t m, const uint32_t *n11, const uint
 int ldx_triangle_dev(const void *alt, const double *fa, const double *fr, const double *q,
                      uint32_t n_snps, uint32_t n_hap, uint64_t unit_begin, uint64_t unit_end,
                      ldx_ld32 *out, ldx_ld64 *out_raw, uint32_t *out_n11, void *stream);
-/* Which kernel ldx_triangle_dev launches.  Both produce identical results (tests compare them cell for
+/* Which kernel ldx_triangle_dev launches.  All produce identical results (tests compare them cell for
  * cell): POPCOUNT = v_and_b32 + v_bcnt_u32_b32 on the bit-packed rows; MFMA = int8 G.G^T on the matrix
- * cores with the bits expanded to bytes in registers.  AUTO picks the one that measures faster. */
+ * cores (v_mfma_i32_32x32x32_i8) with the bits expanded to bytes in registers; FP4 = the same contraction on
+ * v_mfma_f32_32x32x64_f8f6f4 with the bits expanded to FP4 nibbles (twice the int8 rate; fp32 accumulation of
+ * 0/1 products is exact below 2^24).  AUTO picks the one that measures fastest (FP4).
+ * ldx_set_triangle_path sets the process-wide default that ldx_triangle_dev reads (atomically) at every call;
+ * ldx_triangle_path_dev takes the path per call. */
 #define LDX_PATH_AUTO 0
 #define LDX_PATH_POPCOUNT 1
 #define LDX_PATH_MFMA 2
+#define LDX_PATH_FP4 3
 int ldx_set_triangle_path(int path);
 int ldx_get_triangle_path(void);
+int ldx_triangle_path_dev(const void *alt, const double *fa, const double *fr, const double *q,
+                          uint32_t n_snps, uint32_t n_hap, uint64_t unit_begin, uint64_t unit_end,
+                          ldx_ld32 *out, ldx_ld64 *out_raw, uint32_t *out_n11, int path, void *stream);
 
 /* Strip output -> dense row-major float32 [n_rows][ld] matrix of one measure with the
  * ld_two_dim semantics of ld_triangle.py:114,223-230: cell = rounded measure, or 0 when
@@ -165,8 +174,8 @@ int ldx_area_dev(const void *alt, const double *fa, const double *fr, const doub
                  double thres, ldx_hit *hits, uint64_t hit_cap, uint64_t *n_hits, void *workspace,
                  size_t workspace_bytes, void *stream);
 size_t ldx_area_workspace_bytes(uint32_t n_snps, uint32_t n_hap, uint32_t n_query);
-/* kernel behind ldx_area_dev: LDX_PATH_AUTO (matrix-pipe band when >= 1/16 of the SNPs are queries, popcount scan
- * otherwise), LDX_PATH_POPCOUNT, LDX_PATH_MFMA; the hit sets are identical */
+/* kernel behind ldx_area_dev: LDX_PATH_AUTO (FP4 matrix-pipe band when >= 1/16 of the SNPs are queries, popcount scan
+ * otherwise), LDX_PATH_POPCOUNT, LDX_PATH_MFMA (int8 band), LDX_PATH_FP4; the hit sets are identical */
 int ldx_set_area_path(int path);
 int ldx_get_area_path(void);
 
@@ -199,6 +208,10 @@ int ldx_probe_andpop_dev(uint32_t *sink, uint32_t blocks, uint32_t threads, uint
  * 1 = v_mfma_i32_16x16x64_i8 (16384 MACs each).  threads <= 256. */
 int ldx_probe_mfma_dev(uint32_t *sink, uint32_t blocks, uint32_t threads, uint32_t iters, int variant,
                        void *stream);
+
+/* Tests / tuning: force the number of passes a matrix-kernel launch hands out as two half-height tickets
+ * (n_short >= 0), or restore the launch heuristic (n_short < 0).  Results do not depend on it. */
+int ldx_debug_force_short_passes(int n_short);
 
 #ifdef __cplusplus
 }

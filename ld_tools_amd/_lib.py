@@ -89,6 +89,8 @@ SIGNATURES = {
     "ldx_pair_counts_dev": (_int, [_vp, _u32, _vp, _u32, _u32, _vp, _sz, _vp]),
     "ldx_ld_from_counts_dev": (_int, [_u32, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ldx_triangle_dev": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u64, _u64, _vp, _vp, _vp, _vp]),
+    "ldx_triangle_path_dev": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u64, _u64, _vp, _vp, _vp, _int, _vp]),
+    "ldx_debug_force_short_passes": (_int, [_int]),
     "ldx_set_triangle_path": (_int, [_int]),
     "ldx_get_triangle_path": (_int, []),
     "ldx_triangle_dense_dev": (_int, [_vp, _u32, _int, _int, _dbl, _u32, _u32, _vp, _sz, _vp]),

@@ -11,6 +11,8 @@
 //      (ld_area.py:174-177,222), the threshold on the ROUNDED measure (ld_area.py:248) and hit append.
 // Hits are appended through per-wave slot batches (one global atomic per 256 slots); unused slots are
 // marked invalid (query == UINT32_MAX).
+#include <atomic>
+
 #include "ldx_common.h"
 #include "ldx_tile.h"
 
@@ -228,16 +230,17 @@ using namespace ldx;
 // which kernel runs ld_area: LDX_PATH_AUTO = the matrix-pipe band when at least 1/16 of the SNPs are queries (it
 // evaluates every pair of the band once for both orders, whatever the query list: 0.52 ms at 100k SNPs, +-1000
 // neighbours, against 8.2 ms x (queries / SNPs) for the popcount scan), the scan of query rows otherwise
-static int g_area_path = LDX_PATH_AUTO;
+static std::atomic<int> g_area_path{LDX_PATH_AUTO};   // process-wide default, read atomically at every call
 
 extern "C" int ldx_set_area_path(int path)
 {
-    LDX_REQUIRE(path == LDX_PATH_AUTO || path == LDX_PATH_POPCOUNT || path == LDX_PATH_MFMA, "unknown path");
-    g_area_path = path;
+    LDX_REQUIRE(path == LDX_PATH_AUTO || path == LDX_PATH_POPCOUNT || path == LDX_PATH_MFMA || path == LDX_PATH_FP4,
+                "unknown path");
+    g_area_path.store(path, std::memory_order_relaxed);
     return LDX_OK;
 }
 
-extern "C" int ldx_get_area_path(void) { return g_area_path; }
+extern "C" int ldx_get_area_path(void) { return g_area_path.load(std::memory_order_relaxed); }
 
 extern "C" size_t ldx_area_workspace_bytes(uint32_t n_snps, uint32_t n_hap, uint32_t n_query)
 {
@@ -265,9 +268,11 @@ extern "C" int ldx_area_dev(const void *alt, const double *fa, const double *fr,
     LDX_REQUIRE(workspace_bytes >= need && workspace_bytes >= area_mfma_workspace_bytes(n_snps),
                 "workspace too small (see ldx_area_workspace_bytes)");
     hipStream_t s = (hipStream_t)stream;
-    if (g_area_path == LDX_PATH_MFMA || (g_area_path == LDX_PATH_AUTO && (uint64_t)n_query * 16u >= n_snps && n_snps >= 2))
+    const int path = g_area_path.load(std::memory_order_relaxed);
+    if (path == LDX_PATH_MFMA || path == LDX_PATH_FP4 ||
+        (path == LDX_PATH_AUTO && (uint64_t)n_query * 16u >= n_snps && n_snps >= 2))
         return area_mfma(alt, fa, fr, q, n_snps, n_hap, positions, queries, n_query, flank, measure, thres, hits, hit_cap,
-                         n_hits, workspace, s);
+                         n_hits, workspace, path != LDX_PATH_MFMA, s);
     const uint32_t qpad = ldx_padded_snps(n_query), T = ldx::n_slabs(n_snps), nch = ldx::n_chunks(n_hap);
     LDX_HIP(hipMemsetAsync(n_hits, 0, sizeof(uint64_t), s));
     area_gather_kernel<<<(qpad + 3u) / 4u, 256, 0, s>>>((const uint4 *)alt, fa, fr, q, positions, queries, n_query, qpad,

@@ -21,7 +21,7 @@ double thres_to_k(double thres);
 
 // ld_triangle on the matrix cores (ldx_mfma.hip); same contract as ldx_triangle_dev after argument checks
 int triangle_mfma(const void *alt, const double *fa, const double *fr, const double *q, uint32_t n_snps, uint32_t n_hap,
-                  uint64_t unit_begin, uint64_t unit_end, ldx_ld32 *out, ldx_ld64 *out_raw, uint32_t *out_n11,
+                  uint64_t unit_begin, uint64_t unit_end, ldx_ld32 *out, ldx_ld64 *out_raw, uint32_t *out_n11, bool fp4,
                   hipStream_t s);
 
 // ld_area on the matrix pipe (ldx_mfma.hip): all (query, opposing) pairs inside the +-flank band through the MFMA
@@ -29,7 +29,7 @@ int triangle_mfma(const void *alt, const double *fa, const double *fr, const dou
 size_t area_mfma_workspace_bytes(uint32_t n_snps);
 int area_mfma(const void *alt, const double *fa, const double *fr, const double *q, uint32_t n_snps, uint32_t n_hap,
               const int64_t *positions, const uint32_t *queries, uint32_t n_query, int64_t flank, int measure, double thres,
-              ldx_hit *hits, uint64_t hit_cap, uint64_t *n_hits, void *workspace, hipStream_t s);
+              ldx_hit *hits, uint64_t hit_cap, uint64_t *n_hits, void *workspace, bool fp4, hipStream_t s);
 
 #define LDX_HIP(call)                                                                       \
     do {                                                                                    \
@@ -50,7 +50,9 @@ int area_mfma(const void *alt, const double *fa, const double *fr, const double 
     } while (0)
 
 __host__ __device__ inline uint32_t n_slabs(uint32_t n_snps) { return (n_snps + kSlab - 1) / kSlab; }
-__host__ __device__ inline uint32_t n_chunks(uint32_t n_hap) { return (n_hap + 127u) / 128u; }
+// chunks of 128 haplotypes per row, allocated in PAIRS (256 haplotypes): the FP4 matrix kernel consumes two chunks
+// per K-block (one per lane half), so a row always holds an even number of chunks; pad chunks are zero bits
+__host__ __device__ inline uint32_t n_chunks(uint32_t n_hap) { return (n_hap + 255u) / 256u * 2u; }
 
 // first unit of j-tile t: t*G - 8*t*(t-1), G = groups in the padded panel
 __host__ __device__ inline uint64_t tile_base(uint64_t t, uint64_t G) { return t * G - 8u * t * (t - 1u); }
@@ -291,8 +293,9 @@ __device__ __forceinline__ ldx_ld32 ld_pair_fast2(double cnt_scaled, const FastC
 // kClean: the caller has established that no operand is degenerate (every count > 0) and that no SNP has missing
 // codes (a + r == n, hence D' <= 1 and r^2 <= 1 up to rounding): the inf test, the int-0 selects and the y < 1e7
 // guard are dropped.
-template <int W, bool kClean = false>
-__device__ __forceinline__ void ld_multi_fast2(const int (&cnt_scaled)[W], const FastConst &k, const FastRow (&r)[W],
+// T = int (the int8 matrix kernel's accumulators, 8 * n11) or float (the FP4 kernel's, n11: exact integers < 2^24)
+template <int W, bool kClean = false, typename T = int>
+__device__ __forceinline__ void ld_multi_fast2(const T (&cnt_scaled)[W], const FastConst &k, const FastRow (&r)[W],
                                                const FastCol (&c)[W], ldx_ld32 (&out)[W], bool (&slow)[W])
 {
     double dn4[W], x[W], y[W], inv[W], w[W], z[W], yd[W], yr[W], kd[W], kr[W], hd[W], hr[W], ed[W], er[W], mx[W];

@@ -30,6 +30,8 @@
 // DESIGN.md section 3.1 has the measurements behind each of these choices.
 #include <stdlib.h>
 
+#include <atomic>
+#include <functional>
 #include <mutex>
 #include <type_traits>
 #include <unordered_map>
@@ -43,6 +45,8 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
 
 // global loads the compiler does not track (see the K loop): the caller waits with s_waitcnt vmcnt(N)
 __device__ __forceinline__ void gload16(v4u &dst, const v4u *p)
@@ -65,7 +69,7 @@ constexpr int kMfmaWaves = 4;   // waves per workgroup; two workgroups per CU
 constexpr int kMfmaThreads = kMfmaWaves * 64;
 constexpr uint32_t kRows64 = 64;              // i-rows per wave unit
 constexpr uint32_t kBRow = 144;               // bytes per expanded j-row in LDS (128 + 16 pad)
-constexpr uint32_t kBBuf = kSlab * kBRow;     // one buffer: 18 KiB
+constexpr uint32_t kBBuf = kSlab * kBRow;     // one buffer: 18 KiB (int8 image; the FP4 image [4 steps][2 halves][128 rows][16 B] is 16 KiB)
 constexpr uint32_t kStat = 6;                  // doubles per SNP in the LDS operand tables (16-byte aligned rows)
 [[maybe_unused]] constexpr uint32_t kStampPasses = 40, kStampStride = 6 + 4 * kStampPasses;   // tuning builds: LDX_STAMP
 
@@ -99,6 +103,25 @@ __device__ __forceinline__ v4i expand16_a(uint32_t word, uint32_t sel0, uint32_t
     return r;
 }
 
+// ---- FP4 (E2M1) operands for v_mfma_f32_32x32x64_f8f6f4: twice the int8 rate (64 haplotypes per 32 cycles) -----------
+// A nibble with ONE bit at position p in {0, 1, 2} reads 0.5 / 1 / 2 (position 3 is the sign: -0), so a haplotype bit
+// becomes the nibble of its own 4-bit group with NO data movement -- one AND per eight haplotypes -- as long as the
+// other operand carries the bit at position 2 - p: every co-occurrence multiplies to 1 and the fp32 accumulators hold
+// n11 exactly (< 2^24).  The K order inside an instruction is free (both operands use the same one): register v of an
+// operand holds haplotypes {v, v + 4, ..., v + 28} of the 32-bit word for v < 2, and {2, 6, ...} / {3, 7, ...} of the
+// word shifted down by two for v = 2, 3.  5 VALU per 32 haplotypes on the A side, 6 on the B side (the int8 forms
+// above: 14 and 24).  tools/probes/fp4rate.hip checks the exactness and the rate on the device.
+__device__ __forceinline__ v4i expand32_a4(uint32_t w)
+{
+    const uint32_t t = w >> 2;
+    return v4i{(int)(w & 0x11111111u), (int)(w & 0x22222222u), (int)(t & 0x11111111u), (int)(t & 0x22222222u)};   // 0.5, 1, 0.5, 1
+}
+__device__ __forceinline__ v4i expand32_b4(uint32_t w)
+{
+    const uint32_t t = w >> 2;
+    return v4i{(int)((w << 2) & 0x44444444u), (int)(w & 0x22222222u), (int)((w) & 0x44444444u), (int)(t & 0x22222222u)};   // 2, 1, 2, 1
+}
+
 // tuning-only build variants (python ld_tools_amd/build.py --out libldx_x.so -DLDX_AB_...; results are wrong)
 #ifdef LDX_AB_NOAEXP
 #define EXPAND_A(x) v4i{(int)(x), 1, 1, 1}
@@ -113,7 +136,7 @@ __device__ __forceinline__ v4i expand16_a(uint32_t word, uint32_t sel0, uint32_t
 #ifdef LDX_AB_NOBWRITE   // no expansion and no LDS write of the j-tile image (what a pre-expanded, DMA-fed image would save)
 #define BWRITE(dst, x) asm volatile("" : : "v"(x))
 #else
-#define BWRITE(dst, x) dst = EXPAND_B(x)
+#define BWRITE(dst, x) dst = (kFp4 ? expand32_b4(x) : EXPAND_B(x))
 #endif
 
 // In-chunk stamps (build with -DLDX_CHUNK_STAMPS on top of -DLDX_TUNING): s_memtime at six points of ONE chunk
@@ -153,6 +176,7 @@ __host__ __device__ inline uint32_t mfma_pass_base(uint32_t t, uint32_t n_slabs)
 // launch_mfma), zeroed before every launch and re-armed by the last workgroup out
 constexpr uint32_t kSchedSlots = 256;
 __device__ uint32_t g_sched[kSchedSlots][2];
+static std::atomic<int> g_forced_short{-1};   // >= 0: number of halved passes per launch (ldx_debug_force_short_passes)
 
 
 // Arguments of the banded (ld_area) use of the kernel: the same passes, K loop and operand staging; the pass list is
@@ -179,7 +203,11 @@ constexpr uint32_t kStatRows = 32;
 constexpr int kWgPerCu = 2;
 constexpr uint32_t kStatRows = kRows64;
 #endif
-template <bool kRaw, bool kN11, bool kArea = false>
+// kFp4: the counting runs on v_mfma_f32_32x32x64_f8f6f4 with FP4 operands (expand32_a4 / expand32_b4) instead of
+// v_mfma_i32_32x32x32_i8: a K-block is then 256 haplotypes -- two 128-haplotype chunks, one per lane half -- in four
+// steps of 64, so the loop below keeps its shape (per step 8 MFMAs, 4 fragment reads, one quarter of the thread's share
+// of a later block's j-tile image) with `nblocks` = nchunks / 2 iterations and ~16 instead of ~28 VALU per step.
+template <bool kRaw, bool kN11, bool kArea = false, bool kFp4 = false>
 __global__ void __launch_bounds__(kMfmaThreads, kArea ? 2 : kWgPerCu)
 triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ fa, const double *__restrict__ fr,
                      const double *__restrict__ q, uint32_t n_snps, uint32_t n_slabs, uint32_t nchunks, double n,
@@ -219,7 +247,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
     const uint32_t sel1 = half ? 0x03030303u : 0x01010101u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     double *rstat = cstat + kSlab * kStat + wave * ((kArea ? kRows64 : kStatRows) * kStat);   // [64][kStat], private to the wave
-    const FastConst fk = fast_const(n, 8.0);
+    const FastConst fk = fast_const(n, kFp4 ? 1.0 : 8.0);   // the int8 accumulators hold 8 * n11, the FP4 ones n11
     // In-kernel stamps (tuning builds, env LDX_STAMPS=file): per wave {HW_ID | XCC_ID << 32, realtime, passes}
     // and per pass {start, prologue done, K loop done, epilogue done} in shader cycles; written to a buffer nothing else reads.
 #ifdef LDX_TUNING
@@ -290,10 +318,12 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
         // triangle: the units of the tile inside [v_begin, v_end); area: the units the window can reach
         const uint64_t seg_begin = kArea ? tb : (v_begin > tb ? v_begin : tb);
         const uint64_t seg_end = kArea ? tb + (aa.g_end[t] > 2u * t ? aa.g_end[t] - 2u * t : 0u) : (v_end < te ? v_end : te);
-        // the j-tile's bits for this thread's expansion share: row tid/2, 8 bytes (tid%2) of each chunk
+        // the j-tile's bits for this thread's expansion share.  int8: row tid/2, 8 bytes (tid%2) of each chunk;
+        // FP4: row tid%128, the whole 16 bytes of chunk 2b + tid/128 of K-block b (that lane half's chunk)
         const uint2 *bsrc = reinterpret_cast<const uint2 *>(alt + (size_t)t * nchunks * kSlab) + tid;
         constexpr uint32_t kBStride = kSlab * 2u;   // uint2 per chunk
-        const uint32_t b_off = (tid >> 1) * kBRow + (tid & 1u) * 64u;
+        const uint32_t b_off = kFp4 ? ((tid >> 7) * kSlab + (tid & 127u)) * 16u : (tid >> 1) * kBRow + (tid & 1u) * 64u;
+        const uint32_t nblocks = kFp4 ? nchunks / 2u : nchunks;   // K-blocks per unit
 
         auto pass_body = [&](auto mm_c) {
             constexpr int MM = decltype(mm_c)::value;   // 32-row accumulator tiles per wave: 2 (a 64-row unit) or 1 (half)
@@ -303,9 +333,14 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
             const uint32_t roff = MM == 1 ? 32u * hsel : 0u;                        // half-height: rows roff .. roff+31 of the unit
             const uint32_t row0 = g64 * kRows64 + roff;
             // this lane's A rows: row0 + 32*m + l32 (both inside one slab: 64 | 128)
-            const uint4 *ai = alt + ((size_t)(row0 / kSlab) * nchunks) * kSlab + (row0 % kSlab) + l32;
+            // FP4: each lane half streams its own chunk of a K-block (half 0: chunk 2b, half 1: chunk 2b + 1)
+            const uint4 *ai = alt + ((size_t)(row0 / kSlab) * nchunks) * kSlab + (row0 % kSlab) + l32 + (kFp4 ? half * kSlab : 0u);
+            constexpr uint32_t kAStride = kFp4 ? 2u * kSlab : kSlab;   // uint4 per K-block
 
-            v16i acc[MM][4];
+            typedef std::conditional_t<kFp4, v16f, v16i> acc_t;
+            typedef std::conditional_t<kFp4, float, int> accel_t;   // one accumulator element: n11 (FP4) or 8 * n11 (int8)
+            auto count_of = [](accel_t x) { if constexpr (kFp4) return (uint32_t)x; else return (uint32_t)x >> 3; };
+            acc_t acc[MM][4];
 #pragma unroll
             for (int m = 0; m < MM; ++m)
 #pragma unroll
@@ -329,7 +364,8 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
 #ifdef LDX_AB_NOBREAD
                     bf[tt] = v4i{(int)(uintptr_t)buf + w + tt, 1, 1, 1};
 #else
-                    bf[tt] = *reinterpret_cast<const v4i *>(buf + (32u * tt + l32) * kBRow + w * 32u + half * 16u);
+                    bf[tt] = kFp4 ? *reinterpret_cast<const v4i *>(buf + (((uint32_t)w * 2u + half) * kSlab + 32u * tt + l32) * 16u)
+                                  : *reinterpret_cast<const v4i *>(buf + (32u * tt + l32) * kBRow + w * 32u + half * 16u);
 #endif
             };
             auto mma8 = [&](const v4i (&af)[MM], const v4i (&bf)[4]) {
@@ -340,7 +376,16 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
 #ifdef LDX_AB_NOMFMA
                         asm volatile("" : "+v"(acc[m][tt]) : "v"(af[m]), "v"(bf[tt]));   // operands stay live, no work
 #else
-                        acc[m][tt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[m], bf[tt], acc[m][tt], 0, 0, 0);
+                    {
+                        if constexpr (kFp4) {
+                            const v8i a8v = {af[m].x, af[m].y, af[m].z, af[m].w, 0, 0, 0, 0};
+                            const v8i b8v = {bf[tt].x, bf[tt].y, bf[tt].z, bf[tt].w, 0, 0, 0, 0};
+                            // cbsz = blgp = 4: FP4 operands (4 registers each); scale operands 0 = the unscaled instruction
+                            acc[m][tt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8v, b8v, acc[m][tt], 4, 4, 0, 0, 0, 0);
+                        } else {
+                            acc[m][tt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[m], bf[tt], acc[m][tt], 0, 0, 0);
+                        }
+                    }
 #endif
             };
             auto interleave = [&]() {   // 8 x {1 MFMA, up to 5 VALU}: the VALU work of a step hides behind its MFMAs
@@ -376,15 +421,35 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 if constexpr (MM == 2) asm volatile("" : "+v"(ar[k][0]), "+v"(ar[k][1]));
                 else asm volatile("" : "+v"(ar[k][0]));
             };
-            v2u br[3];      // this thread's 8 bytes of the j-tile's chunk (B expansion share)
-            auto clampc = [&](uint32_t c) { return c < nchunks ? c : nchunks - 1u; };   // surplus loads are discarded
+            typedef std::conditional_t<kFp4, v4u, v2u> bring_t;
+            bring_t br[3];   // this thread's bits of the j-tile's K-block (B expansion share): 8 bytes (int8) / 16 bytes (FP4)
+            auto clampc = [&](uint32_t c) { return c < nblocks ? c : nblocks - 1u; };   // surplus loads are discarded
+            auto load_b = [&](bring_t &dst, uint32_t blk) {
+                if constexpr (kFp4)
+                    gload16(dst, reinterpret_cast<const v4u *>(alt + ((size_t)t * nchunks + 2u * blk + (tid >> 7)) * kSlab + (tid & 127u)));
+                else
+                    gload8(dst, bsrc + (size_t)blk * kBStride);
+            };
+            // quarter q (K step q) of this thread's share of a K-block, expanded into the image at `buf`
+            auto bquarter = [&](unsigned char *buf, const bring_t &bits, int q) {
+                if constexpr (kFp4) {
+                    BWRITE(*reinterpret_cast<v4i *>(buf + b_off + (uint32_t)q * (2u * kSlab * 16u)), bits[q]);
+                } else {
+                    const uint32_t w = q < 2 ? bits.x : bits.y;
+                    BWRITE(*reinterpret_cast<v4i *>(buf + b_off + (uint32_t)q * 16u), (q & 1) ? w >> 16 : w);
+                }
+            };
+            auto expand_a = [&](uint32_t x) {   // one K step of this lane's A row: its 16 (int8) / 32 (FP4) haplotype bits of word x
+                if constexpr (kFp4) return expand32_a4(x);
+                else return EXPAND_A(x);
+            };
             {
-                v2u w0;
-                gload8(w0, bsrc);
-                gload8(br[1], bsrc + (size_t)clampc(1) * kBStride);
+                bring_t w0;
+                load_b(w0, 0u);
+                load_b(br[1], clampc(1));
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
-                    const v4u *src = reinterpret_cast<const v4u *>(ai + (size_t)clampc(k) * kSlab);
+                    const v4u *src = reinterpret_cast<const v4u *>(ai + (size_t)clampc(k) * kAStride);
                     gload16(ar[k][0], src);
                     if constexpr (MM == 2) gload16_512(ar[k][1], src);
                 }
@@ -392,13 +457,10 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 asm volatile("" : "+v"(w0), "+v"(br[1]));
                 touch_ring(0);
                 touch_ring(1);
-                v4i *d0 = reinterpret_cast<v4i *>(bexp + b_off);   // chunk 0 -> buffer 0
-                d0[0] = expand16(w0.x);
-                d0[1] = expand16(w0.x >> 16);
-                d0[2] = expand16(w0.y);
-                d0[3] = expand16(w0.y >> 16);
-                // quarter 0 of chunk 1 -> buffer 1 (in the loop it is written during step 3 of the chunk before)
-                *reinterpret_cast<v4i *>(bexp + kBBuf + b_off) = expand16(br[1].x);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bquarter(bexp, w0, q);   // K-block 0 -> buffer 0
+                // quarter 0 of K-block 1 -> buffer 1 (in the loop it is written during step 3 of the block before)
+                bquarter(bexp + kBBuf, br[1], 0);
             }
             bool rows_ordinary = false;
             if (!kRaw) {   // epilogue operands -> LDS (every wave is past its previous epilogue: barrier above)
@@ -430,9 +492,9 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
             v4i af0[MM], bf0[4], af1[MM], bf1[4];
             read_bf(bf0, bexp, 0);
 #pragma unroll
-            for (int m = 0; m < MM; ++m) af0[m] = EXPAND_A(ar[0][m].x);
+            for (int m = 0; m < MM; ++m) af0[m] = expand_a(ar[0][m].x);
 
-            const uint32_t nch_run = (ablate & 2) ? 1u : nchunks;
+            const uint32_t nch_run = (ablate & 2) ? 1u : nblocks;
 #ifdef LDX_CHUNK_STAMPS
             unsigned long long cst[6] = {0, 0, 0, 0, 0, 0};
 #endif
@@ -443,54 +505,53 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 const uint32_t c_ = (cc);                                                                          \
                 const unsigned char *rd = bexp + (c_ & 1u) * kBBuf;                                                \
                 unsigned char *wr = bexp + ((c_ + 1u) & 1u) * kBBuf;                                               \
-                v4i *bdst = reinterpret_cast<v4i *>(wr + b_off);                                                   \
                 const uint32_t c3 = clampc(c_ + 2u);                                                               \
                 LDX_CSTAMP(0)                                                                                      \
-                /* loads of chunk c+2, B bits FIRST (vmcnt counts in issue order).  In flight now, oldest first: */ \
-                /* chunk c+1's {B, A, A} and this batch's {B, A, A}; step 0 needs the former B: 5 may stay */       \
-                gload8(br[FAR], bsrc + (size_t)c3 * kBStride);                                                     \
+                /* loads of K-block c+2, B bits FIRST (vmcnt counts in issue order).  In flight now, oldest first: */ \
+                /* block c+1's {B, A, A} and this batch's {B, A, A}; step 0 needs the former B: 5 may stay */       \
+                load_b(br[FAR], c3);                                                                               \
                 {                                                                                                  \
-                    const v4u *src_ = reinterpret_cast<const v4u *>(ai + (size_t)c3 * kSlab);                      \
+                    const v4u *src_ = reinterpret_cast<const v4u *>(ai + (size_t)c3 * kAStride);                   \
                     gload16(ar[FAR][0], src_);                                                                     \
                     if constexpr (MM == 2) gload16_512(ar[FAR][1], src_);                                          \
                 }                                                                                                  \
                 asm volatile("s_waitcnt vmcnt(%0)" : : "n"(MM == 2 ? 5 : 3));   /* all but the 1 + MM newest pairs */ \
                 asm volatile("" : "+v"(br[NXT]));                                                                  \
-                /* step 0: MFMAs of (c,0); prepare (c,1); quarter 1 of this thread's share of B chunk c+1 */      \
+                /* step 0: MFMAs of (c,0); prepare (c,1); quarter 1 of this thread's share of B block c+1 */      \
                 read_bf(bf1, rd, 1);                                                                               \
-                _Pragma("unroll") for (int m = 0; m < MM; ++m) af1[m] = EXPAND_A(ar[CUR][m].y);               \
-                BWRITE(bdst[1], br[NXT].x >> 16);                                                                  \
+                _Pragma("unroll") for (int m = 0; m < MM; ++m) af1[m] = expand_a(ar[CUR][m].y);               \
+                bquarter(wr, br[NXT], 1);                                                                          \
                 mma8(af0, bf0);                                                                                    \
                 interleave();                                                                                      \
                 __builtin_amdgcn_sched_barrier(0);                                                                 \
                 LDX_CSTAMP(1)                                                                                      \
                 /* step 1: MFMAs of (c,1); prepare (c,2); quarter 2 of the B share */                             \
                 read_bf(bf0, rd, 2);                                                                               \
-                _Pragma("unroll") for (int m = 0; m < MM; ++m) af0[m] = EXPAND_A(ar[CUR][m].z);               \
-                BWRITE(bdst[2], br[NXT].y);                                                                        \
+                _Pragma("unroll") for (int m = 0; m < MM; ++m) af0[m] = expand_a(ar[CUR][m].z);               \
+                bquarter(wr, br[NXT], 2);                                                                          \
                 mma8(af1, bf1);                                                                                    \
                 interleave();                                                                                      \
                 __builtin_amdgcn_sched_barrier(0);                                                                 \
                 LDX_CSTAMP(2)                                                                                      \
                 /* step 2: MFMAs of (c,2); prepare (c,3); quarter 3 of the B share */                             \
                 read_bf(bf1, rd, 3);                                                                               \
-                _Pragma("unroll") for (int m = 0; m < MM; ++m) af1[m] = EXPAND_A(ar[CUR][m].w);               \
-                BWRITE(bdst[3], br[NXT].y >> 16);                                                                  \
+                _Pragma("unroll") for (int m = 0; m < MM; ++m) af1[m] = expand_a(ar[CUR][m].w);               \
+                bquarter(wr, br[NXT], 3);                                                                          \
                 mma8(af0, bf0);                                                                                    \
                 interleave();                                                                                      \
                 __builtin_amdgcn_sched_barrier(0);                                                                 \
                 LDX_CSTAMP(3)                                                                                      \
-                lds_barrier(); /* chunk c+1 complete in `wr`; nobody reads `rd` any more */                       \
+                lds_barrier(); /* block c+1 complete in `wr`; nobody reads `rd` any more */                       \
                 LDX_CSTAMP(4)                                                                                      \
-                /* step 3: MFMAs of (c,3); prepare (c+1,0) from the other buffer and the next A chunk, whose */   \
-                /* words must have landed; quarter 0 of the B share of chunk c+2 goes into the buffer of chunk c, */ \
-                /* which nobody reads any more.  Only this chunk's two A loads may still be in flight. */           \
+                /* step 3: MFMAs of (c,3); prepare (c+1,0) from the other buffer and the next A block, whose */   \
+                /* words must have landed; quarter 0 of the B share of block c+2 goes into the buffer of block c, */ \
+                /* which nobody reads any more.  Only this block's two A loads may still be in flight. */           \
                 asm volatile("s_waitcnt vmcnt(%0)" : : "n"(MM));                                                   \
                 touch_ring(NXT);                                                                                   \
                 asm volatile("" : "+v"(br[FAR]));                                                                  \
                 read_bf(bf0, wr, 0);                                                                               \
-                _Pragma("unroll") for (int m = 0; m < MM; ++m) af0[m] = EXPAND_A(ar[NXT][m].x);               \
-                BWRITE(*reinterpret_cast<v4i *>(bexp + (c_ & 1u) * kBBuf + b_off), br[FAR].x);                  \
+                _Pragma("unroll") for (int m = 0; m < MM; ++m) af0[m] = expand_a(ar[NXT][m].x);               \
+                bquarter(bexp + (c_ & 1u) * kBBuf, br[FAR], 0);                                                    \
                 mma8(af1, bf1);                                                                                    \
                 interleave();                                                                                      \
                 __builtin_amdgcn_sched_barrier(0);                                                                 \
@@ -580,7 +641,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                         for (int tt = 0; tt < 4; ++tt) {
                             const uint32_t j = t * kSlab + 32u * tt + l32;
                             valid[m][tt] = (i > j) && (i < n_snps);
-                            cnt[m][tt] = (uint32_t)acc[m][tt][e] >> 3;
+                            cnt[m][tt] = count_of(acc[m][tt][e]);
                             const LdRaw lr = ld_epilogue((double)cnt[m][tt] / n, fa1, fr1, q1, fa2[tt], fr2[tt]);   // calc_ld.py:33
                             res[m][tt] = round_pair(lr);
                             rw[m][tt] = valid[m][tt] ? ldx_ld64{lr.rsq, lr.dprime} : ldx_ld64{0.0, 0.0};
@@ -617,7 +678,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                             nxt[1] = MM == 2 ? nxt[0] : load_col(chain_tt(pp + 1, 1));
                         }
                         FastRow frk[2];
-                        int a8[2];
+                        accel_t a8[2];
                         ldx_ld32 r2[2];
                         bool s2[2];
 #pragma unroll
@@ -627,7 +688,6 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                             const uint32_t i = row0 + ri[m], j = t * kSlab + 32u * tt + l32;
                             valid[m][tt] = kClean || ((i > j) && (i < n_snps));
                             a8[k] = acc[m][tt][e];
-                            cnt[m][tt] = (uint32_t)a8[k] >> 3;
                         }
                         if (ablate & 1) {   // tuning: no epilogue arithmetic
 #pragma unroll
@@ -653,7 +713,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                             for (int tt = 0; tt < 4; ++tt)
                                 if (slow[m][tt]) {
                                     const uint32_t i = row0 + ri[m], j = t * kSlab + 32u * tt + l32;
-                                    res[m][tt] = ld_pair_mirror((double)cnt[m][tt] / n, fa[i], fr[i], q[i], fa[j], fr[j]);
+                                    res[m][tt] = ld_pair_mirror((double)count_of(acc[m][tt][e]) / n, fa[i], fr[i], q[i], fa[j], fr[j]);
                                 }
                     }
                 }
@@ -668,7 +728,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                             if (!kClean && !valid[m][tt]) w = ldx_ld32{0.0f, 0.0f};
                             out[o] = w;
                             if (kRaw) raw[o] = rw[m][tt];
-                            if (kN11) n11[o] = valid[m][tt] ? cnt[m][tt] : 0u;
+                            if (kN11) n11[o] = valid[m][tt] ? count_of(acc[m][tt][e]) : 0u;
                         }
                     }
             }
@@ -728,7 +788,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                         const FastCol fcx[2] = {FastCol{c01.x, c01.y, c23.x, c23.y}, FastCol{c01.x, c01.y, c23.x, c23.y}};
                         const double pj = c45.x, qj = c45.y;
                         const uint32_t j = t * kSlab + 32u * tt + l32;
-                        int a8[2];
+                        accel_t a8[2];
                         ldx_ld32 r2[2];
                         bool s2[2];
 #pragma unroll
@@ -769,7 +829,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                             ldx_ld32 ra = r2[m], rb = r2[m];
                             if (__builtin_expect(__any(s2[m] && (in_a || in_b)), 0)) {
                                 if (s2[m] && (in_a || in_b)) {
-                                    const double f11 = (double)((uint32_t)a8[m] >> 3) / n;
+                                    const double f11 = (double)count_of(a8[m]) / n;
                                     ra = ld_pair_mirror(f11, fa[i], fr[i], q[i], fa[j], fr[j]);
                                     rb = ld_pair_mirror(f11, fa[j], fr[j], q[j], fa[i], fr[i]);
                                 }
@@ -825,40 +885,59 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
             if (sl < aa.hit_cap) aa.hits[sl].query = 0xFFFFFFFFu;
 }
 
-// One ticket-counter pair per STREAM (launches of one stream are ordered, so they may share it; launches of different
-// streams may overlap, so they must not), zeroed on the stream before every launch: a kernel that was killed
-// mid-flight cannot leave stale tickets behind.  The kernel's own re-arming stays as a second line.
+// One ticket-counter pair per (device, stream): launches of one stream are ordered, so they may share it; launches of
+// different streams (or devices) may overlap, so they must not.  The pairs live in the per-device instance of g_sched;
+// a slot is zeroed ONCE, on the stream that acquires it, and from then on every launch leaves it re-armed (the last
+// workgroup out resets both words), so a launch costs no memset node.
 static int acquire_sched(hipStream_t s, uint32_t **sched)
 {
-    static uint32_t (*sched_pool)[2] = nullptr;
+    struct Key {
+        int dev;
+        hipStream_t s;
+        bool operator==(const Key &o) const { return dev == o.dev && s == o.s; }
+    };
+    struct KeyHash {
+        size_t operator()(const Key &k) const { return std::hash<void *>()((void *)k.s) * 31u + (size_t)k.dev; }
+    };
+    struct PerDevice {
+        uint32_t (*pool)[2] = nullptr;   // this device's g_sched
+        uint32_t next_slot = 0;
+        Key owner[kSchedSlots] = {};
+    };
     static std::mutex sched_mutex;
-    static std::unordered_map<hipStream_t, uint32_t> sched_slot;
+    static std::unordered_map<Key, uint32_t, KeyHash> sched_slot;
+    static PerDevice per_dev[64];
+    int dev = 0;
+    LDX_HIP(hipGetDevice(&dev));
+    LDX_REQUIRE(dev >= 0 && dev < 64, "device ordinal out of range");
+    bool fresh = false;
     uint32_t slot;
     {
         std::lock_guard<std::mutex> lock(sched_mutex);
-        if (!sched_pool) {
+        PerDevice &pd = per_dev[dev];
+        if (!pd.pool) {
             void *sym = nullptr;
-            LDX_HIP(hipGetSymbolAddress(&sym, HIP_SYMBOL(g_sched)));
-            sched_pool = reinterpret_cast<uint32_t (*)[2]>(sym);
+            LDX_HIP(hipGetSymbolAddress(&sym, HIP_SYMBOL(g_sched)));   // the current device's copy of the symbol
+            pd.pool = reinterpret_cast<uint32_t (*)[2]>(sym);
         }
-        static uint32_t next_slot = 0;
-        static hipStream_t owner[kSchedSlots] = {};
-        auto it = sched_slot.find(s);
+        const Key key{dev, s};
+        auto it = sched_slot.find(key);
         if (it == sched_slot.end()) {   // a new stream takes the next slot round-robin; the slot's previous owner (a
-            slot = next_slot++ % kSchedSlots;   // stream last seen >= 256 new streams ago) loses its entry
-            if (next_slot > kSchedSlots) sched_slot.erase(owner[slot]);
-            owner[slot] = s;
-            sched_slot.emplace(s, slot);
+            slot = pd.next_slot++ % kSchedSlots;   // stream last seen >= 256 new streams ago) loses its entry
+            if (pd.next_slot > kSchedSlots) sched_slot.erase(pd.owner[slot]);
+            pd.owner[slot] = key;
+            sched_slot.emplace(key, slot);
+            fresh = true;
         } else {
             slot = it->second;
         }
+        *sched = pd.pool[slot];
     }
-    *sched = sched_pool[slot];
-    LDX_HIP(hipMemsetAsync(*sched, 0, 2 * sizeof(uint32_t), s));
+    if (fresh) LDX_HIP(hipMemsetAsync(*sched, 0, 2 * sizeof(uint32_t), s));
     return LDX_OK;
 }
 
-template <bool kRaw, bool kN11>
+template <bool kRaw, bool kN11, bool kFp4>
 static int launch_mfma(const void *alt, const double *fa, const double *fr, const double *q, uint32_t n_snps,
                        uint32_t n_hap, uint64_t unit_begin, uint64_t unit_end, ldx_ld32 *out, ldx_ld64 *out_raw,
                        uint32_t *out_n11, hipStream_t s)
@@ -889,8 +968,8 @@ static int launch_mfma(const void *alt, const double *fa, const double *fr, cons
     // Measured at 10 000 x 5008 (1580 passes on 512 workgroups): 128 halved passes -3 %, 256..384 -1 %, all +13 %.
     // A launch of at most half a round (tiny panels) halves every pass: -20 % at 1000-2000 SNPs.
     uint32_t n_short = 2ull * n_pass <= slots ? n_pass : (n_pass > slots ? (uint32_t)(slots / 4u) : 0u);
-    if (const char *env = getenv("LDX_SHORT"))   // tuning / tests: force the number of halved passes
-        n_short = (uint32_t)atoi(env) < n_pass ? (uint32_t)atoi(env) : n_pass;
+    const int forced = g_forced_short.load(std::memory_order_relaxed);   // tests / tuning: ldx_debug_force_short_passes
+    if (forced >= 0) n_short = (uint32_t)forced < n_pass ? (uint32_t)forced : n_pass;
 #ifdef LDX_MM1
     n_short = n_pass;
 #endif
@@ -910,7 +989,7 @@ static int launch_mfma(const void *alt, const double *fa, const double *fr, cons
         LDX_HIP(hipMemsetAsync(stamps, 0, stamp_words * 8, s));
     }
 #endif
-    triangle_mfma_kernel<kRaw, kN11><<<(uint32_t)grid, kMfmaThreads, lds, s>>>(
+    triangle_mfma_kernel<kRaw, kN11, false, kFp4><<<(uint32_t)grid, kMfmaThreads, lds, s>>>(
         (const uint4 *)alt, fa, fr, q, n_snps, n_slabs(n_snps), nch, (double)n_hap, 1.0 / (double)n_hap, unit_begin,
         unit_end, out, out_raw, out_n11, p_begin, p_end, n_short, sched, ablate, stamps, AreaArgs{});
     LDX_HIP(hipGetLastError());
@@ -933,16 +1012,17 @@ static int launch_mfma(const void *alt, const double *fa, const double *fr, cons
 }
 
 int triangle_mfma(const void *alt, const double *fa, const double *fr, const double *q, uint32_t n_snps, uint32_t n_hap,
-                  uint64_t unit_begin, uint64_t unit_end, ldx_ld32 *out, ldx_ld64 *out_raw, uint32_t *out_n11,
+                  uint64_t unit_begin, uint64_t unit_end, ldx_ld32 *out, ldx_ld64 *out_raw, uint32_t *out_n11, bool fp4,
                   hipStream_t s)
 {
-    if (out_raw && out_n11)
-        return launch_mfma<true, true>(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end, out, out_raw, out_n11, s);
-    if (out_raw)
-        return launch_mfma<true, false>(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end, out, out_raw, out_n11, s);
-    if (out_n11)
-        return launch_mfma<false, true>(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end, out, out_raw, out_n11, s);
-    return launch_mfma<false, false>(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end, out, out_raw, out_n11, s);
+#define LDX_GO(R, N)                                                                                                    \
+    return fp4 ? launch_mfma<R, N, true>(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end, out, out_raw, out_n11, s) \
+               : launch_mfma<R, N, false>(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end, out, out_raw, out_n11, s)
+    if (out_raw && out_n11) LDX_GO(true, true);
+    if (out_raw) LDX_GO(true, false);
+    if (out_n11) LDX_GO(false, true);
+    LDX_GO(false, false);
+#undef LDX_GO
 }
 
 }  // namespace ldx
@@ -1003,7 +1083,7 @@ size_t area_mfma_workspace_bytes(uint32_t n_snps)
 
 int area_mfma(const void *alt, const double *fa, const double *fr, const double *q, uint32_t n_snps, uint32_t n_hap,
               const int64_t *positions, const uint32_t *queries, uint32_t n_query, int64_t flank, int measure, double thres,
-              ldx_hit *hits, uint64_t hit_cap, uint64_t *n_hits, void *workspace, hipStream_t s)
+              ldx_hit *hits, uint64_t hit_cap, uint64_t *n_hits, void *workspace, bool fp4, hipStream_t s)
 {
     const uint32_t T = n_slabs(n_snps), nch = n_chunks(n_hap);
     char *w = (char *)workspace;
@@ -1034,9 +1114,14 @@ int area_mfma(const void *alt, const double *fa, const double *fr, const double 
     aa.k_thres = thres_to_k(thres);
     aa.measure = measure;
     const uint64_t units = ldx_triangle_units(n_snps) / 8u;   // 64-row units of the full triangle
-    triangle_mfma_kernel<false, false, true><<<(uint32_t)cus * 2u, kMfmaThreads, lds, s>>>(
-        (const uint4 *)alt, fa, fr, q, n_snps, T, nch, (double)n_hap, 1.0 / (double)n_hap, 0, units * 8u, nullptr, nullptr,
-        nullptr, 0u, 0u, 0u, sched, 0, nullptr, aa);
+    if (fp4)
+        triangle_mfma_kernel<false, false, true, true><<<(uint32_t)cus * 2u, kMfmaThreads, lds, s>>>(
+            (const uint4 *)alt, fa, fr, q, n_snps, T, nch, (double)n_hap, 1.0 / (double)n_hap, 0, units * 8u, nullptr,
+            nullptr, nullptr, 0u, 0u, 0u, sched, 0, nullptr, aa);
+    else
+        triangle_mfma_kernel<false, false, true, false><<<(uint32_t)cus * 2u, kMfmaThreads, lds, s>>>(
+            (const uint4 *)alt, fa, fr, q, n_snps, T, nch, (double)n_hap, 1.0 / (double)n_hap, 0, units * 8u, nullptr,
+            nullptr, nullptr, 0u, 0u, 0u, sched, 0, nullptr, aa);
     LDX_HIP(hipGetLastError());
     return LDX_OK;
 }
@@ -1093,5 +1178,11 @@ extern "C" int ldx_probe_mfma_dev(uint32_t *sink, uint32_t blocks, uint32_t thre
     else
         ldx::probe_mfma_kernel<1><<<blocks, threads, 0, (hipStream_t)stream>>>(sink, iters);
     LDX_HIP(hipGetLastError());
+    return LDX_OK;
+}
+
+extern "C" int ldx_debug_force_short_passes(int n_short)
+{
+    ldx::g_forced_short.store(n_short < 0 ? -1 : n_short, std::memory_order_relaxed);
     return LDX_OK;
 }

@@ -14,6 +14,8 @@
 //     (t-major), so a tile is staged once per workgroup per tile; units are dealt round-robin to the
 //     waves (all units cost the same, so a static deal is as good as a queue and needs no LDS word:
 //     at 5008 haplotypes the tile alone is 80 KiB).
+#include <atomic>
+
 #include "ldx_common.h"
 #include "ldx_tile.h"
 
@@ -237,16 +239,23 @@ __global__ void __launch_bounds__(1024) probe_andpop_kernel(uint32_t *__restrict
 
 using namespace ldx;
 
-static int g_triangle_path = LDX_PATH_AUTO;
+// process-wide default kernel of ldx_triangle_dev (read atomically at every call; ldx_triangle_path_dev takes the
+// path as an argument instead)
+static std::atomic<int> g_triangle_path{LDX_PATH_AUTO};
+
+static bool known_path(int path)
+{
+    return path == LDX_PATH_AUTO || path == LDX_PATH_POPCOUNT || path == LDX_PATH_MFMA || path == LDX_PATH_FP4;
+}
 
 extern "C" int ldx_set_triangle_path(int path)
 {
-    LDX_REQUIRE(path == LDX_PATH_AUTO || path == LDX_PATH_POPCOUNT || path == LDX_PATH_MFMA, "unknown path");
-    g_triangle_path = path;
+    LDX_REQUIRE(known_path(path), "unknown path");
+    g_triangle_path.store(path, std::memory_order_relaxed);
     return LDX_OK;
 }
 
-extern "C" int ldx_get_triangle_path(void) { return g_triangle_path; }
+extern "C" int ldx_get_triangle_path(void) { return g_triangle_path.load(std::memory_order_relaxed); }
 
 static size_t tile_lds_bytes(uint32_t nchunks) { return (size_t)nchunks * kSlab * 16u; }
 
@@ -283,7 +292,16 @@ extern "C" int ldx_triangle_dev(const void *alt, const double *fa, const double 
                                 uint32_t n_snps, uint32_t n_hap, uint64_t unit_begin, uint64_t unit_end,
                                 ldx_ld32 *out, ldx_ld64 *out_raw, uint32_t *out_n11, void *stream)
 {
+    return ldx_triangle_path_dev(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end, out, out_raw, out_n11,
+                                 g_triangle_path.load(std::memory_order_relaxed), stream);
+}
+
+extern "C" int ldx_triangle_path_dev(const void *alt, const double *fa, const double *fr, const double *q,
+                                     uint32_t n_snps, uint32_t n_hap, uint64_t unit_begin, uint64_t unit_end,
+                                     ldx_ld32 *out, ldx_ld64 *out_raw, uint32_t *out_n11, int path, void *stream)
+{
     LDX_REQUIRE(alt && fa && fr && q && out, "null pointer");
+    LDX_REQUIRE(known_path(path), "unknown path");
     LDX_REQUIRE(n_snps >= 1 && n_hap >= 1, "bad shape");
     if (n_hap > LDX_MAX_HAPS) {
         set_error("ldx_triangle_dev: n_hap %u > LDX_MAX_HAPS %u", n_hap, LDX_MAX_HAPS);
@@ -297,8 +315,9 @@ extern "C" int ldx_triangle_dev(const void *alt, const double *fa, const double 
     if (unit_end > U) unit_end = U;
     if (unit_begin >= unit_end) return LDX_OK;
     hipStream_t s = (hipStream_t)stream;
-    if (g_triangle_path == LDX_PATH_MFMA || g_triangle_path == LDX_PATH_AUTO)
-        return triangle_mfma(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end, out, out_raw, out_n11, s);
+    if (path != LDX_PATH_POPCOUNT)   // AUTO = the FP4 matrix kernel (twice the int8 kernel's counting rate)
+        return triangle_mfma(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end, out, out_raw, out_n11,
+                             path != LDX_PATH_MFMA, s);
     if (out_raw && out_n11)
         return launch_triangle<true, true>(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end, out, out_raw, out_n11, s);
     if (out_raw)

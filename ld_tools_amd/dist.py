@@ -23,6 +23,11 @@ SLAB = 128
 GROUP = 8
 
 
+def n_chunks(n_hap: int) -> int:
+    """Same arithmetic as ldx_n_chunks (include/ldx.h): 128-haplotype chunks per row, allocated in pairs."""
+    return (n_hap + 255) // 256 * 2
+
+
 def slab_partition(n_snps: int, world: int) -> List[Tuple[int, int]]:
     """Rows [begin, end) packed by each rank: whole slabs, ceil(n_slabs / world) per rank until they run out
     (only the last ranks get fewer, possibly none), covering [0, n_snps).  With this shape the rank-major
@@ -211,7 +216,7 @@ def all_gather_panel(local, n_snps: int, n_hap: int, group=None, out=None, with_
     parts = slab_partition(n_snps, world)
     dev = local.device if local is not None else require_gpu()
     full = out if out is not None else PackedPanel.empty(n_snps, n_hap, dev)
-    slab_bytes = ((n_hap + 127) // 128) * SLAB * 16
+    slab_bytes = n_chunks(n_hap) * SLAB * 16
     slabs = [(e - b + SLAB - 1) // SLAB for (b, e) in parts]
     fd = {"alt": full.alt, "acnt": full.acnt, "rcnt": full.rcnt}
     ld = None if local is None else {"alt": local.alt, "acnt": local.acnt, "rcnt": local.rcnt}
@@ -241,7 +246,7 @@ class PanelPipeline:
         self.world = dist.get_world_size(group)
         parts = slab_partition(n_snps, self.world)
         self.slabs = [(e - b + SLAB - 1) // SLAB for (b, e) in parts]
-        self.slab_bytes = ((n_hap + 127) // 128) * SLAB * 16
+        self.slab_bytes = n_chunks(n_hap) * SLAB * 16
         self.panels = [PackedPanel.empty(n_snps, n_hap, device) for _ in range(2)]
         self.stages = [None, None]
         self.device = device

@@ -21,7 +21,7 @@ from ._lib import MEASURES, UNIT_PAIRS, check, lib
 from .panel import PackedPanel, _ptr, _stream_ptr
 
 
-PATHS = {"auto": 0, "popcount": 1, "mfma": 2}
+PATHS = {"auto": 0, "popcount": 1, "mfma": 2, "fp4": 3}
 
 
 def set_triangle_path(name: str) -> None:

@@ -25,7 +25,7 @@ from oracle import c_oracle  # noqa: E402
 def tiled_plane(codes: np.ndarray, n_hap: int) -> np.ndarray:
     """uint8 tiled ALT plane of include/ldx.h for int8 codes [rows][n_hap] (rows padded to slabs)."""
     rows = codes.shape[0]
-    slabs, chunks = (rows + 127) // 128, (n_hap + 127) // 128
+    slabs, chunks = (rows + 127) // 128, ldist.n_chunks(n_hap)
     bits = np.zeros((slabs * 128, chunks * 128), dtype=np.uint8)
     bits[:rows, :n_hap] = codes == 1
     by = np.packbits(bits, axis=1, bitorder="little").reshape(slabs, 128, chunks, 16)
@@ -42,7 +42,7 @@ def main():
         mine = synth.synth_codes_host(e - b, n_hap, seed=3, miss=0.01, snp_offset=b)   # rank-local ingest
         assert np.array_equal(mine, full_codes[b:e])
         shard = torch.from_numpy(tiled_plane(mine, n_hap))
-        slab_bytes = ((n_hap + 127) // 128) * 128 * 16
+        slab_bytes = ldist.n_chunks(n_hap) * 128 * 16
         sizes = [((pe - pb + 127) // 128) * slab_bytes for (pb, pe) in parts]
         dst = torch.zeros(sum(sizes), dtype=torch.uint8)
         ldist.gather_shards(dst, shard, sizes)

@@ -55,8 +55,8 @@ def test_geometry_helpers():
         if n > 1:
             assert L.ldx_triangle_unit_of(n, n - 1, 0) == (n - 1) // 8
             assert L.ldx_triangle_unit_of(n, n - 1, n - 2) < L.ldx_triangle_units(n)
-    for h in (1, 128, 129, 1008, 5008):
-        assert L.ldx_n_chunks(h) == (h + 127) // 128
+    for h in (1, 128, 129, 256, 257, 1008, 5008, 10240):     # 128-haplotype chunks, allocated in pairs
+        assert L.ldx_n_chunks(h) == 2 * ((h + 255) // 256) == dist.n_chunks(h)
     assert L.ldx_plane_bytes(10000, 5008) == 79 * 40 * 128 * 16
     # cells >= pairs, with less than 4 % padding at the bench size
     cells = L.ldx_triangle_units(10000) * 1024

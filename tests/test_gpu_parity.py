@@ -26,9 +26,9 @@ def gpu():
     return torch.device("cuda", 0)
 
 
-@pytest.fixture(params=["popcount", "mfma"])
+@pytest.fixture(params=["popcount", "mfma", "fp4"])
 def path(request, gpu):
-    """Run a triangle test once per kernel: AND+BCNT on the VALU, and int8 MFMA."""
+    """Run a triangle test once per kernel: AND+BCNT on the VALU, int8 MFMA, FP4 MFMA (the default)."""
     from ld_tools_amd import ops
 
     ops.set_triangle_path(request.param)
@@ -38,13 +38,13 @@ def path(request, gpu):
 
 def untile(plane_u8: np.ndarray, n_snps: int, n_hap: int) -> np.ndarray:
     """tiled plane bytes -> bool [n_snps][n_hap]"""
-    slabs, chunks = (n_snps + 127) // 128, (n_hap + 127) // 128
+    slabs, chunks = (n_snps + 127) // 128, (n_hap + 255) // 256 * 2   # chunks are allocated in pairs
     by = plane_u8.reshape(slabs, chunks, 128, 16).transpose(0, 2, 1, 3).reshape(slabs * 128, chunks * 16)
     bits = np.unpackbits(by, axis=1, bitorder="little")
     return bits[:n_snps, :n_hap].astype(bool), bits
 
 
-@pytest.fixture(params=["popcount", "mfma"])
+@pytest.fixture(params=["popcount", "mfma", "fp4"])
 def area_path(request, gpu):
     """Run an ld_area test once per kernel (the popcount scan of query rows and the matrix-pipe band)."""
     from ld_tools_amd import ops
@@ -343,19 +343,20 @@ def test_popcount_and_mfma_kernels_agree_bitwise(gpu):
     p = PackedPanel.from_codes(synth.synth_codes_device(1500, 5008, seed=21, miss=0.004))
     ops.set_triangle_path("popcount")
     a = ld_triangle(p, want_raw=True, want_n11=True)
-    ops.set_triangle_path("mfma")
-    b = ld_triangle(p, want_raw=True, want_n11=True)
-    ops.set_triangle_path("auto")
-    assert torch.equal(a.n11, b.n11)
-    assert torch.equal(a.ld32.view(torch.int32), b.ld32.view(torch.int32))      # incl. the -0.0f int-0 marks
-    assert torch.equal(a.raw.view(torch.int64), b.raw.view(torch.int64))
-    # ragged unit ranges (not multiples of 8 small units) on the MFMA path
-    ops.set_triangle_path("mfma")
-    parts = [(0, 13), (13, 1001), (1001, p.n_units)]
-    pieces = [ld_triangle(p, unit_range=r, want_n11=True) for r in parts]
-    ops.set_triangle_path("auto")
-    assert torch.equal(torch.cat([x.n11 for x in pieces]), a.n11)
-    assert torch.equal(torch.cat([x.ld32 for x in pieces]).view(torch.int32), a.ld32.view(torch.int32))
+    for mm in ("mfma", "fp4"):
+        ops.set_triangle_path(mm)
+        b = ld_triangle(p, want_raw=True, want_n11=True)
+        ops.set_triangle_path("auto")
+        assert torch.equal(a.n11, b.n11), mm
+        assert torch.equal(a.ld32.view(torch.int32), b.ld32.view(torch.int32)), mm      # incl. the -0.0f int-0 marks
+        assert torch.equal(a.raw.view(torch.int64), b.raw.view(torch.int64)), mm
+        # ragged unit ranges (not multiples of 8 small units) on the matrix paths
+        ops.set_triangle_path(mm)
+        parts = [(0, 13), (13, 1001), (1001, p.n_units)]
+        pieces = [ld_triangle(p, unit_range=r, want_n11=True) for r in parts]
+        ops.set_triangle_path("auto")
+        assert torch.equal(torch.cat([x.n11 for x in pieces]), a.n11), mm
+        assert torch.equal(torch.cat([x.ld32 for x in pieces]).view(torch.int32), a.ld32.view(torch.int32)), mm
 
 
 def test_too_many_haplotypes_is_an_error(gpu):
@@ -406,7 +407,7 @@ def test_triangle_bench_size_against_oracle_rows(gpu, path):
 
 def test_triangle_random_shapes_both_kernels_and_oracle(gpu):
     """Forty seeded random shapes (1..1400 SNPs, 1..2600 haplotypes, with and without missing codes and monomorphic
-    rows): the two kernels agree bit for bit on every cell, and the MFMA kernel equals the C oracle on all of them."""
+    rows): the three kernels agree bit for bit on every cell, and the FP4 kernel equals the C oracle on all of them."""
     import torch
     from ld_tools_amd import PackedPanel, ld_triangle, ops, synth
     from oracle import c_oracle
@@ -422,14 +423,15 @@ def test_triangle_random_shapes_both_kernels_and_oracle(gpu):
                 codes[rng.randint(n)] = rng.randint(2)          # a monomorphic row
             p = PackedPanel.from_codes(codes)
             got = {}
-            for path in ("mfma", "popcount"):
+            for path in ("fp4", "mfma", "popcount"):
                 ops.set_triangle_path(path)
                 r = ld_triangle(p, want_n11=True)
                 got[path] = (r.ld32.clone().view(torch.int32), r.n11.clone(), r)
-            assert torch.equal(got["mfma"][0], got["popcount"][0]) and torch.equal(got["mfma"][1], got["popcount"][1]), (n, h, miss)
+            for mm in ("mfma", "fp4"):
+                assert torch.equal(got[mm][0], got["popcount"][0]) and torch.equal(got[mm][1], got["popcount"][1]), (n, h, miss, mm)
             if n >= 2:
                 rows, cols = np.tril_indices(n, -1)
-                res = got["mfma"][2]
+                res = got["fp4"][2]
                 idx = res.cell_index(rows, cols)
                 o = c_oracle.Panel(codes).triangle(libm_pow=True, want=("n11", "rsq_rnd", "dp_rnd", "flags"))
                 ld32 = res.ld32.cpu().numpy()[idx]
@@ -442,20 +444,26 @@ def test_triangle_random_shapes_both_kernels_and_oracle(gpu):
         ops.set_triangle_path("auto")
 
 
-def test_triangle_half_height_tickets_agree(gpu, monkeypatch):
-    """Whole passes, all passes halved (two 32-row tickets each) and a mix give identical results (LDX_SHORT forces the
-    number of halved passes; by default only tiny launches and the last quarter round of large ones are halved)."""
+def test_triangle_half_height_tickets_agree(gpu, path):
+    """Whole passes, all passes halved (two 32-row tickets each) and a mix give identical results
+    (ldx_debug_force_short_passes forces the number of halved passes; by default only tiny launches and the last quarter
+    round of large ones are halved)."""
     import torch
     from ld_tools_amd import PackedPanel, ld_triangle, synth
+    from ld_tools_amd._lib import lib
 
+    if path == "popcount":
+        pytest.skip("tickets are a matrix-kernel matter")
     for n, h, miss in [(3000, 5008, 0.0), (1111, 777, 0.01)]:
         p = PackedPanel.from_codes(synth.synth_codes_device(n, h, seed=9, miss=miss))
         got = []
-        for short in ("0", "1000000", "37"):
-            monkeypatch.setenv("LDX_SHORT", short)
-            r = ld_triangle(p, want_n11=True)
-            got.append((r.ld32.clone().view(torch.int32), r.n11.clone()))
-        monkeypatch.delenv("LDX_SHORT")
+        try:
+            for short in (0, 1000000, 37):
+                lib.ldx_debug_force_short_passes(short)
+                r = ld_triangle(p, want_n11=True)
+                got.append((r.ld32.clone().view(torch.int32), r.n11.clone()))
+        finally:
+            lib.ldx_debug_force_short_passes(-1)
         for a, b in got[1:]:
             assert torch.equal(a, got[0][0]) and torch.equal(b, got[0][1])
 
@@ -495,16 +503,17 @@ def test_triangle_100k_shard_of_eight(gpu):
     p = PackedPanel.from_codes(codes_d)
     u0, u1 = dist.unit_partition(n, 8)[3]
     try:
-        ops.set_triangle_path("mfma")
+        ops.set_triangle_path("fp4")
         a = ld_triangle(p, unit_range=(u0, u1), want_n11=True)
-        ops.set_triangle_path("popcount")
-        b = ld_triangle(p, unit_range=(u0, u1), want_n11=True)
+        for other in ("popcount", "mfma"):
+            ops.set_triangle_path(other)
+            b = ld_triangle(p, unit_range=(u0, u1), want_n11=True)
+            assert torch.equal(a.n11, b.n11), other
+            assert torch.equal(a.ld32.view(torch.int32), b.ld32.view(torch.int32)), other
+            del b
     finally:
         ops.set_triangle_path("auto")
     assert a.ld32.shape[0] == (u1 - u0) * UNIT_PAIRS
-    assert torch.equal(a.n11, b.n11)
-    assert torch.equal(a.ld32.view(torch.int32), b.ld32.view(torch.int32))
-    del b
     # cells of a few rows that lie inside the shard, against the oracle
     codes = codes_d.cpu().numpy()
     o = c_oracle.Panel(codes)
@@ -615,14 +624,16 @@ def test_area_paths_agree(gpu):
     try:
         for queries, flank, measure, thres in cases:
             got = {}
-            for path in ("popcount", "mfma"):
+            for path in ("popcount", "mfma", "fp4"):
                 ops.set_area_path(path)
                 hits = ld_area(p, pos, queries, flank, measure, thres)
                 got[path] = (hits.query.cpu().numpy(), hits.oppos.cpu().numpy(), hits.ld32.cpu().numpy().view(np.uint32),
                              hits.n_pairs)
-            a, b = got["popcount"], got["mfma"]
-            assert a[3] == b[3] and len(a[0]) == len(b[0]), (flank, measure, thres, len(a[0]), len(b[0]))
-            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+            a = got["popcount"]
+            for mm in ("mfma", "fp4"):
+                b = got[mm]
+                assert a[3] == b[3] and len(a[0]) == len(b[0]), (mm, flank, measure, thres, len(a[0]), len(b[0]))
+                assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), mm
     finally:
         ops.set_area_path("auto")
 
@@ -647,7 +658,7 @@ def test_area_random_cases_both_kernels_and_oracle(gpu):
             o = c_oracle.Panel(codes)
             qs = np.arange(n) if queries is None else np.array(queries)
             hq, ho, hr, hd, hf = o.area(pos, qs, flank, 0 if measure == "r_square" else 1, thres, libm_pow=True)
-            for path in ("popcount", "mfma"):
+            for path in ("popcount", "mfma", "fp4"):
                 ops.set_area_path(path)
                 hits = ld_area(p, pos, queries, flank, measure, thres)
                 tag = (case, n, h, flank, measure, thres, path)
