@@ -61,11 +61,24 @@ extern "C" {
 #define LDX_MEASURE_RSQ 0
 #define LDX_MEASURE_DPRIME 1
 
-/* One result cell of the canonical 8-byte/pair output: round(r_square, 4) and round(d_prime, 4)
- * of calc_ld.py:94-95 as the float32 nearest to k/10^4.  A value that is the reference's int 0
- * is stored as -0.0f (sign bit set), a float 0.0 as +0.0f, so str() can be reproduced. */
+/* Result cells.  The reference returns round(r_square, 4) and round(d_prime, 4) (calc_ld.py:94-95), i.e. k / 10^4
+ * for an integer k, or the *int* 0 in the degenerate branches.  Two cell formats carry (k, int-0 mark) per value:
+ *   ldx_ld32 (8 bytes/pair): the float32 nearest to k / 10^4; int 0 is -0.0f (sign bit set), a float 0.0 is +0.0f.
+ *            k = rint(value * 10^4) is exact while value < 1024 (float32 ulp below 10^-4).  Larger values -- they
+ *            arise only with missing codes, where a + r < n lets the bound of D' vanish -- are stored as the quiet
+ *            NaN LDX_LD32_BIG_BITS: fetch the exact value with ldx_ld_pairs_dev.
+ *   ldx_k16  (4 bytes/pair): k itself in bits 0..14 of a uint16 (host: k / 10^4 in double IS Python's round(x, 4)),
+ *            bit 15 set (LDX_K16_INT0) for the int 0; k >= 32767 (value >= 3.2767) is stored as LDX_K16_BIG: fetch
+ *            the exact value with ldx_ld_pairs_dev.
+ * str() of every value can be reproduced from either. */
 typedef struct { float r_square; float d_prime; } ldx_ld32;
+typedef struct { uint16_t r_square; uint16_t d_prime; } ldx_k16;
 typedef struct { double r_square; double d_prime; } ldx_ld64;   /* unrounded, for parity checks */
+#define LDX_LD32_BIG_BITS 0x7FC00B16u   /* ldx_ld32 value >= 1024: a quiet NaN with this payload */
+#define LDX_K16_INT0 0x8000u
+#define LDX_K16_BIG 0x7FFFu
+#define LDX_OUT_LD32 0
+#define LDX_OUT_K16 1
 
 /* one ld_area hit (ld_area.py:261-271): query/opposing SNP row indices and rounded values */
 typedef struct {
@@ -123,6 +136,22 @@ int ldx_pair_counts_dev(const void *alt_i, uint32_t n_i, const void *alt_j, uint
 int ldx_ld_from_counts_dev(uint32_t n, size_t m, const uint32_t *n11, const uint32_t *a1,
                            const uint32_t *r1, const uint32_t *a2, const uint32_t *r2,
                            ldx_ld64 *raw, ldx_ld32 *rounded, uint8_t *flags, void *stream);
+/* The same with every output form: k = round(x, 4) * 10^4 as doubles [m][2] (r_square, d_prime; exact for any
+ * magnitude), and the two cell formats.  The cells come from the production epilogues of the pair kernels (every tier:
+ * fp32 / count-domain fp64 / op-for-op mirror), which must agree with each other bit for bit -- a disagreement poisons
+ * the cell (NaN / 0xFFFF) so that the exhaustive tests fail loudly.  Any output may be NULL. */
+int ldx_ld_from_counts_ex_dev(uint32_t n, size_t m, const uint32_t *n11, const uint32_t *a1,
+                              const uint32_t *r1, const uint32_t *a2, const uint32_t *r2,
+                              ldx_ld64 *raw, double *k, ldx_ld32 *cells32, ldx_k16 *cells16, uint8_t *flags,
+                              void *stream);
+
+/* ---- LD of an explicit list of pairs of one panel: calc_ld.py:30-97 per pair, exact for any magnitude ---- */
+/* Pair p = (var_1 = rows[p], var_2 = cols[p]).  k: double [m][2] = round(x, 4) * 10^4 for (r_square, d_prime);
+ * raw: unrounded; flags: LDX_FLAG_*; n11: the alt/alt haplotype counts.  Any output may be NULL.  This is how the
+ * escape cells of the two formats are resolved, and what ld_lite-style single lookups use. */
+int ldx_ld_pairs_dev(const void *alt, const uint32_t *acnt, const uint32_t *rcnt, uint32_t n_snps, uint32_t n_hap,
+                     const uint32_t *rows, const uint32_t *cols, size_t m, double *k, ldx_ld64 *raw,
+                     uint8_t *flags, uint32_t *n11, void *stream);
 
 /* ---- ld_triangle: all row > col pairs (ld_triangle.py:133-230) ------------------------- */
 /* Computes work units [unit_begin, unit_end) (clamped to ldx_triangle_units()).  var_1 = row,
@@ -145,9 +174,11 @@ int ldx_triangle_dev(const void *alt, const double *fa, const double *fr, const 
 #define LDX_PATH_FP4 3
 int ldx_set_triangle_path(int path);
 int ldx_get_triangle_path(void);
-int ldx_triangle_path_dev(const void *alt, const double *fa, const double *fr, const double *q,
-                          uint32_t n_snps, uint32_t n_hap, uint64_t unit_begin, uint64_t unit_end,
-                          ldx_ld32 *out, ldx_ld64 *out_raw, uint32_t *out_n11, int path, void *stream);
+/* ldx_triangle_dev with the kernel path and the cell format per call.  out: ldx_ld32 or ldx_k16 cells
+ * (out_format = LDX_OUT_LD32 / LDX_OUT_K16), indexed as in ldx_triangle_dev.  out_raw needs LDX_OUT_LD32. */
+int ldx_triangle_ex_dev(const void *alt, const double *fa, const double *fr, const double *q,
+                        uint32_t n_snps, uint32_t n_hap, uint64_t unit_begin, uint64_t unit_end,
+                        int path, int out_format, void *out, ldx_ld64 *out_raw, uint32_t *out_n11, void *stream);
 
 /* Strip output -> dense row-major float32 [n_rows][ld] matrix of one measure with the
  * ld_two_dim semantics of ld_triangle.py:114,223-230: cell = rounded measure, or 0 when
@@ -155,6 +186,11 @@ int ldx_triangle_path_dev(const void *alt, const double *fa, const double *fr, c
 int ldx_triangle_dense_dev(const ldx_ld32 *strips, uint32_t n_snps, int measure, int has_thres,
                            double thres, uint32_t row_begin, uint32_t row_end, float *dense,
                            size_t ld, void *stream);
+/* The same for either cell format (strips_format = LDX_OUT_LD32 / LDX_OUT_K16).  Escape cells (values the format
+ * cannot hold) come out as the NaN LDX_LD32_BIG_BITS whatever the threshold: resolve them with ldx_ld_pairs_dev. */
+int ldx_triangle_dense_ex_dev(const void *strips, int strips_format, uint32_t n_snps, int measure, int has_thres,
+                              double thres, uint32_t row_begin, uint32_t row_end, float *dense,
+                              size_t ld, void *stream);
 
 /* ---- ld_area: windowed scan around query SNPs (ld_area.py:152-276) --------------------- */
 /* positions: int64 [n_snps] ascending 1-based coordinates (VCF order).  queries: uint32 row
@@ -191,8 +227,10 @@ int ldx_synth_codes_dev(int8_t *codes, uint32_t n_snps, uint32_t n_hap, size_t l
 
 /* ---- host-pointer conveniences (same kernels; allocate, copy, synchronise) ------------- */
 /* calc_ld for ONE pair of code vectors of lengths h1, h2 (zip semantics of calc_ld.py:30-31:
- * n = min(h1, h2) for the haplotype count, allele counts over the full vectors).
- * counts[6] = {n, n11, a1, r1, a2, r2}; raw/rounded as above; freq4[2] = round4(fa1), round4(fa2). */
+ * n = min(h1, h2) for the haplotype count, allele counts over the full vectors; any lengths >= 1).
+ * counts[6] = {n, n11, a1, r1, a2, r2}; raw = unrounded; rounded = round(x, 4) as doubles, exact for any
+ * magnitude; freq4[2] = round4(fa1), round4(fa2).  One H2D copy, ONE kernel (counts straight from the codes,
+ * epilogue, rounding) and one 64-byte D2H copy per call, through device scratch cached per host thread. */
 int ldx_calc_ld_host(const int8_t *g1, uint32_t h1, const int8_t *g2, uint32_t h2,
                      uint32_t counts[6], ldx_ld64 *raw, ldx_ld64 *rounded, double freq4[2],
                      uint8_t *flags);

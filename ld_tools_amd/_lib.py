@@ -22,6 +22,10 @@ MAX_HAPS = 10240
 FLAG_DPRIME_INT0 = 1
 FLAG_RSQ_INT0 = 2
 MEASURES = {"r_square": 0, "d_prime": 1}
+FORMATS = {"ld32": 0, "k16": 1}          # LDX_OUT_LD32 / LDX_OUT_K16
+LD32_BIG_BITS = 0x7FC00B16               # ldx_ld32 escape (value >= 1024): a quiet NaN
+K16_INT0 = 0x8000
+K16_BIG = 0x7FFF
 INVALID_ROW = 0xFFFFFFFF
 
 E_NAMES = {-1: "LDX_E_ARG", -2: "LDX_E_HIP", -3: "LDX_E_UNSUPPORTED", -4: "LDX_E_OVERFLOW"}
@@ -89,7 +93,10 @@ SIGNATURES = {
     "ldx_pair_counts_dev": (_int, [_vp, _u32, _vp, _u32, _u32, _vp, _sz, _vp]),
     "ldx_ld_from_counts_dev": (_int, [_u32, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ldx_triangle_dev": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u64, _u64, _vp, _vp, _vp, _vp]),
-    "ldx_triangle_path_dev": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u64, _u64, _vp, _vp, _vp, _int, _vp]),
+    "ldx_triangle_ex_dev": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u64, _u64, _int, _int, _vp, _vp, _vp, _vp]),
+    "ldx_triangle_dense_ex_dev": (_int, [_vp, _int, _u32, _int, _int, _dbl, _u32, _u32, _vp, _sz, _vp]),
+    "ldx_ld_from_counts_ex_dev": (_int, [_u32, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ldx_ld_pairs_dev": (_int, [_vp, _vp, _vp, _u32, _u32, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     "ldx_debug_force_short_passes": (_int, [_int]),
     "ldx_set_triangle_path": (_int, [_int]),
     "ldx_get_triangle_path": (_int, []),

@@ -47,20 +47,35 @@ def build(force: bool = False, save_temps: bool = False, verbose: bool = True, o
     if not force and not stale() and out == LIB:
         return LIB
     tmp_lib = out.with_name(f"{out.name}.tmp.{os.getpid()}")
-    cmd = [hipcc(), *FLAGS, *defines, *[str(CSRC / s) for s in SOURCES], "-o", str(tmp_lib)]
-    cwd = PKG
-    if save_temps:   # the .s / .bc files land in ld_tools_amd/build/ (git-ignored)
-        cwd = PKG / "build"
-        cwd.mkdir(exist_ok=True)
-        cmd += ["-save-temps=cwd", "-Rpass-analysis=kernel-resource-usage"]
+    cwd = PKG / "build"
+    cwd.mkdir(exist_ok=True)
+    tag = f"{out.stem}.{os.getpid()}"
+    objs = [cwd / f"{Path(s).stem}.{tag}.o" for s in SOURCES]
+    compile_flags = [f for f in FLAGS if f != "-shared"]
+    extra = ["-save-temps=cwd", "-Rpass-analysis=kernel-resource-usage"] if save_temps else []   # .s / .bc land in build/
+    cmds = [[hipcc(), *compile_flags, *defines, *extra, "-c", str(CSRC / s), "-o", str(o)] for s, o in zip(SOURCES, objs)]
+    link = [hipcc(), "-shared", "-fPIC", "--offload-arch=gfx950", *[str(o) for o in objs], "-o", str(tmp_lib)]
     if verbose:
-        print("[ldx build]", " ".join(cmd), file=sys.stderr)
+        for c in cmds + [link]:
+            print("[ldx build]", " ".join(c), file=sys.stderr)
     try:
-        subprocess.run(cmd, check=True, cwd=str(cwd))
+        # one hipcc per source file, side by side (the matrix kernel's instantiations dominate: minutes in one process)
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(c):
+            return subprocess.run(c, cwd=str(cwd), capture_output=not verbose and not save_temps, text=True)
+
+        with ThreadPoolExecutor(max_workers=min(len(cmds), os.cpu_count() or 1)) as pool:
+            results = list(pool.map(run, cmds))
+        for c, r in zip(cmds, results):
+            if r.returncode != 0:
+                raise RuntimeError(f"hipcc failed ({r.returncode}): {' '.join(c)}\n{r.stderr or ''}")
+        subprocess.run(link, check=True, cwd=str(cwd))
         os.replace(tmp_lib, out)   # atomic: a concurrent loader sees the old or the new file, never half
     finally:
-        if tmp_lib.exists():
-            tmp_lib.unlink()
+        for f in [tmp_lib, *objs]:
+            if f.exists():
+                f.unlink()
     return out
 
 

@@ -101,14 +101,87 @@ extern "C" uint64_t ldx_triangle_unit_of(uint32_t n_snps, uint32_t row, uint32_t
     return tile_base(t, T * kGroupsPerSlab) + (g - t * kGroupsPerSlab);
 }
 
-// ---- calc_ld for one pair, host pointers (used by the backend/calc_ld.py drop-in) ----
-namespace {
-struct DevBuf {
-    void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int alloc(size_t n) { LDX_HIP(hipMalloc(&p, n)); return LDX_OK; }
+// ---- calc_ld for one pair, host pointers (used by the backend/calc_ld.py drop-in; ld_lite.py:143) ----
+namespace ldx {
+
+struct CalcLdRecord {       // the 64 bytes that travel back
+    uint32_t counts[6];     // n, n11, a1, r1, a2, r2
+    uint32_t flags;
+    uint32_t pad;
+    double raw[2];          // r_square, d_prime unrounded
+    double k[2];            // round(x, 4) * 10^4
+    double freq4[2];        // round(fa1, 4), round(fa2, 4)
 };
-}  // namespace
+static_assert(sizeof(CalcLdRecord) == 80, "record layout");
+
+// One workgroup: the five counts of calc_ld.py:30-40 straight from the two code vectors (zip semantics: n11 over the
+// common prefix, allele counts over each full vector), then the op-for-op epilogue with real divisions and the exact
+// 4-decimal rounding on one lane.
+__global__ void __launch_bounds__(1024) calc_ld_pair_kernel(const int8_t *__restrict__ g1, uint32_t h1,
+                                                            const int8_t *__restrict__ g2, uint32_t h2,
+                                                            CalcLdRecord *__restrict__ rec)
+{
+    __shared__ uint32_t part[16][5];
+    const uint32_t hmax = h1 > h2 ? h1 : h2, hmin = h1 < h2 ? h1 : h2;
+    uint32_t c[5] = {0, 0, 0, 0, 0};   // n11, a1, r1, a2, r2
+    for (uint32_t h = threadIdx.x; h < hmax; h += blockDim.x) {
+        const int x = h < h1 ? g1[h] : 2, y = h < h2 ? g2[h] : 2;
+        c[0] += (h < hmin) & (x == 1) & (y == 1);
+        c[1] += x == 1;
+        c[2] += x == 0;
+        c[3] += y == 1;
+        c[4] += y == 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) c[k] += __shfl_xor(c[k], off);
+        if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6][k] = c[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t[5] = {0, 0, 0, 0, 0};
+        for (uint32_t w = 0; w < blockDim.x / 64u; ++w)
+            for (int k = 0; k < 5; ++k) t[k] += part[w][k];
+        const double n = (double)hmin;
+        const double fa1 = (double)t[1] / n, fr1 = (double)t[2] / n, fa2 = (double)t[3] / n, fr2 = (double)t[4] / n;
+        const LdRaw lr = ld_epilogue((double)t[0] / n, fa1, fr1, fa1 * fr1, fa2, fr2);
+        CalcLdRecord r;
+        r.counts[0] = hmin;
+        for (int k = 0; k < 5; ++k) r.counts[k + 1] = t[k];
+        r.flags = lr.flags;
+        r.pad = 0;
+        r.raw[0] = lr.rsq;
+        r.raw[1] = lr.dprime;
+        r.k[0] = round4_k(lr.rsq);
+        r.k[1] = round4_k(lr.dprime);
+        r.freq4[0] = round4_k(fa1) / 1e4;
+        r.freq4[1] = round4_k(fa2) / 1e4;
+        *rec = r;
+    }
+}
+
+// device scratch of the calling host thread (grown on demand, released when the thread ends)
+struct CalcLdScratch {
+    int dev = -1;
+    void *codes = nullptr;
+    size_t cap = 0;
+    CalcLdRecord *rec = nullptr;
+    hipStream_t stream = nullptr;
+    void release()
+    {
+        if (codes) (void)hipFree(codes);
+        if (rec) (void)hipFree(rec);
+        if (stream) (void)hipStreamDestroy(stream);
+        codes = nullptr;
+        rec = nullptr;
+        stream = nullptr;
+        cap = 0;
+    }
+    ~CalcLdScratch() { release(); }
+};
+
+}  // namespace ldx
 
 extern "C" int ldx_calc_ld_host(const int8_t *g1, uint32_t h1, const int8_t *g2, uint32_t h2,
                                 uint32_t counts[6], ldx_ld64 *raw, ldx_ld64 *rounded, double freq4[2],
@@ -116,55 +189,44 @@ extern "C" int ldx_calc_ld_host(const int8_t *g1, uint32_t h1, const int8_t *g2,
 {
     LDX_REQUIRE(g1 && g2 && counts, "null pointer");
     LDX_REQUIRE(h1 >= 1 && h2 >= 1, "empty genotype vector (the reference raises ZeroDivisionError, calc_ld.py:33)");
-    const uint32_t hmax = h1 > h2 ? h1 : h2, n = h1 < h2 ? h1 : h2;
-    if (hmax > LDX_MAX_HAPS) {
-        set_error("ldx_calc_ld_host: %u haplotypes > LDX_MAX_HAPS %u", hmax, LDX_MAX_HAPS);
-        return LDX_E_UNSUPPORTED;
+    static thread_local CalcLdScratch sc;
+    int dev = 0;
+    LDX_HIP(hipGetDevice(&dev));
+    if (sc.dev != dev) {   // first call of this thread, or the thread switched devices
+        sc.release();
+        sc.dev = dev;
     }
-    // a 2-row panel of width hmax; the shorter vector is padded with code 2 (neither plane), so the AND over
-    // the full width equals the zipped-prefix count of calc_ld.py:30-32 while a/r cover the full vectors (:37-40)
-    const size_t ld = ((size_t)hmax + 15u) & ~(size_t)15u;
-    std::vector<int8_t> codes(2 * ld, (int8_t)2);
-    memcpy(codes.data(), g1, h1);
-    memcpy(codes.data() + ld, g2, h2);
-    const size_t pb = ldx_plane_bytes(2, hmax);
-    const uint32_t npad = ldx_padded_snps(2);
-    DevBuf dcodes, dalt, dref, dcnt, dn11, dsix, draw, drnd, dfl, dfreq;
-    int rc;
-    if ((rc = dcodes.alloc(codes.size())) || (rc = dalt.alloc(pb)) || (rc = dref.alloc(pb)) ||
-        (rc = dcnt.alloc(2 * npad * sizeof(uint32_t))) || (rc = dn11.alloc(4 * sizeof(uint32_t))) ||
-        (rc = dsix.alloc(5 * sizeof(uint32_t))) || (rc = draw.alloc(sizeof(ldx_ld64))) ||
-        (rc = drnd.alloc(sizeof(ldx_ld32))) || (rc = dfl.alloc(16)) || (rc = dfreq.alloc(npad * sizeof(double))))
-        return rc;
-    uint32_t *acnt = (uint32_t *)dcnt.p, *rcnt = acnt + npad;
-    LDX_HIP(hipMemcpy(dcodes.p, codes.data(), codes.size(), hipMemcpyHostToDevice));
-    if ((rc = ldx_pack_codes_dev((const int8_t *)dcodes.p, 2, hmax, ld, dalt.p, dref.p, acnt, rcnt, nullptr))) return rc;
-    if ((rc = ldx_pair_counts_dev(dalt.p, 2, dalt.p, 2, hmax, (uint32_t *)dn11.p, 2, nullptr))) return rc;
-    if ((rc = ldx_alt_freq4_dev(acnt, 2, n, (double *)dfreq.p, nullptr))) return rc;
-    uint32_t hn11[4], ha[2], hr[2];
-    LDX_HIP(hipMemcpy(hn11, dn11.p, sizeof(hn11), hipMemcpyDeviceToHost));
-    LDX_HIP(hipMemcpy(ha, acnt, sizeof(ha), hipMemcpyDeviceToHost));
-    LDX_HIP(hipMemcpy(hr, rcnt, sizeof(hr), hipMemcpyDeviceToHost));
-    counts[0] = n; counts[1] = hn11[1]; counts[2] = ha[0]; counts[3] = hr[0]; counts[4] = ha[1]; counts[5] = hr[1];
-    // the epilogue runs on the device from the six integers (n is the zipped length)
-    uint32_t *six = (uint32_t *)dsix.p;
-    LDX_HIP(hipMemcpy(six, counts + 1, 5 * sizeof(uint32_t), hipMemcpyHostToDevice));
-    if ((rc = ldx_ld_from_counts_dev(n, 1, six, six + 1, six + 2, six + 3, six + 4, (ldx_ld64 *)draw.p,
-                                     (ldx_ld32 *)drnd.p, (uint8_t *)dfl.p, nullptr)))
-        return rc;
-    ldx_ld64 hraw;
-    ldx_ld32 hrnd;
-    uint8_t hfl;
-    LDX_HIP(hipMemcpy(&hraw, draw.p, sizeof(hraw), hipMemcpyDeviceToHost));
-    LDX_HIP(hipMemcpy(&hrnd, drnd.p, sizeof(hrnd), hipMemcpyDeviceToHost));
-    LDX_HIP(hipMemcpy(&hfl, dfl.p, 1, hipMemcpyDeviceToHost));
-    if (raw) *raw = hraw;
-    if (flags) *flags = hfl;
-    if (rounded) {
-        // the float32 cell is the one nearest to k/10^4: hand back k/10^4 itself as a double
-        rounded->r_square = rint((double)hrnd.r_square * 1e4) / 1e4;
-        rounded->d_prime = rint((double)hrnd.d_prime * 1e4) / 1e4;
+    const size_t need = ((size_t)h1 + 15u) / 16u * 16u + h2;
+    if (!sc.rec) {
+        LDX_HIP(hipMalloc((void **)&sc.rec, sizeof(CalcLdRecord)));
+        LDX_HIP(hipStreamCreateWithFlags(&sc.stream, hipStreamNonBlocking));
     }
-    if (freq4) LDX_HIP(hipMemcpy(freq4, dfreq.p, 2 * sizeof(double), hipMemcpyDeviceToHost));
+    if (need > sc.cap) {
+        if (sc.codes) LDX_HIP(hipFree(sc.codes));
+        sc.codes = nullptr;
+        sc.cap = 0;
+        const size_t cap = need < 65536 ? 65536 : need * 2;
+        LDX_HIP(hipMalloc(&sc.codes, cap));
+        sc.cap = cap;
+    }
+    int8_t *d1 = (int8_t *)sc.codes, *d2 = d1 + ((size_t)h1 + 15u) / 16u * 16u;
+    LDX_HIP(hipMemcpyAsync(d1, g1, h1, hipMemcpyHostToDevice, sc.stream));
+    LDX_HIP(hipMemcpyAsync(d2, g2, h2, hipMemcpyHostToDevice, sc.stream));
+    calc_ld_pair_kernel<<<1, 1024, 0, sc.stream>>>(d1, h1, d2, h2, sc.rec);
+    LDX_HIP(hipGetLastError());
+    CalcLdRecord r;
+    LDX_HIP(hipMemcpyAsync(&r, sc.rec, sizeof(r), hipMemcpyDeviceToHost, sc.stream));
+    LDX_HIP(hipStreamSynchronize(sc.stream));
+    for (int k = 0; k < 6; ++k) counts[k] = r.counts[k];
+    if (raw) *raw = ldx_ld64{r.raw[0], r.raw[1]};
+    if (flags) *flags = (uint8_t)r.flags;
+    if (rounded) {   // k / 10^4 in double IS Python's round(x, 4): the double nearest to the decimal k * 10^-4
+        rounded->r_square = r.k[0] / 1e4;
+        rounded->d_prime = r.k[1] / 1e4;
+    }
+    if (freq4) {
+        freq4[0] = r.freq4[0];
+        freq4[1] = r.freq4[1];
+    }
     return LDX_OK;
 }

@@ -187,10 +187,9 @@ area_scan_kernel(const uint4 *__restrict__ alt, const uint4 *__restrict__ qalt, 
                         ldx_ld32 res = {0.0f, 0.0f};
                         if (keep) {
                             const LdRaw lr = ld_epilogue((double)acc.v[r][jj] / n, fa1, fr1, q1, fa2[jj], fr2[jj]);
-                            const double kr = round4_k(lr.rsq), kd = round4_k(lr.dprime);
-                            keep = (measure == LDX_MEASURE_RSQ ? kr : kd) >= k_thres;   // ld_area.py:248
-                            res.r_square = encode32(kr, (lr.flags & LDX_FLAG_RSQ_INT0) != 0);
-                            res.d_prime = encode32(kd, (lr.flags & LDX_FLAG_DPRIME_INT0) != 0);
+                            const LdK lk = round_pair(lr);
+                            keep = (measure == LDX_MEASURE_RSQ ? lk.kr : lk.kd) >= k_thres;   // ld_area.py:248
+                            res = encode_cell<ldx_ld32>(lk);
                         }
                         const unsigned long long m = __ballot(keep);
                         if (m) {   // wave-uniform

@@ -5,6 +5,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <type_traits>
+
 #include "../../include/ldx.h"
 
 namespace ldx {
@@ -21,8 +23,8 @@ double thres_to_k(double thres);
 
 // ld_triangle on the matrix cores (ldx_mfma.hip); same contract as ldx_triangle_dev after argument checks
 int triangle_mfma(const void *alt, const double *fa, const double *fr, const double *q, uint32_t n_snps, uint32_t n_hap,
-                  uint64_t unit_begin, uint64_t unit_end, ldx_ld32 *out, ldx_ld64 *out_raw, uint32_t *out_n11, bool fp4,
-                  hipStream_t s);
+                  uint64_t unit_begin, uint64_t unit_end, int out_format, void *out, ldx_ld64 *out_raw, uint32_t *out_n11,
+                  bool fp4, hipStream_t s);
 
 // ld_area on the matrix pipe (ldx_mfma.hip): all (query, opposing) pairs inside the +-flank band through the MFMA
 // kernel; same hit contract as the popcount scan of ldx_area.hip
@@ -104,24 +106,58 @@ __device__ inline double round4_k(double x)
     return up ? k + 1.0 : k;
 }
 
-// float32 nearest to k/10^4; an int-0 result carries the sign bit (-0.0f).
-__device__ inline float encode32(double k, bool int0)
-{
-    float v = (float)(k * 1e-4);
-    return int0 ? -0.0f : v;
-}
+// ---- result cells.  A rounded result is the integer k = round(x, 4) * 10^4 (a double: without missing codes k <= 10^4,
+// with them D' and r^2 have no upper bound) plus the int-0 mark.  Two cell formats carry it (include/ldx.h):
+//   ldx_ld32: two float32 nearest to k / 10^4, -0.0f = int 0; identifies k while k < kBig32 (value < 1024, float32 ulp
+//             below 10^-4); larger values are stored as the quiet NaN LDX_LD32_BIG ("fetch the exact value": ldx_ld_pairs_dev)
+//   ldx_k16:  two uint16: k in bits 0..14, bit 15 = int 0; k >= 32767 is stored as the escape LDX_K16_BIG (0x7FFF)
+struct LdK {
+    double kr, kd;      // k of r_square, d_prime
+    uint32_t flags;     // LDX_FLAG_RSQ_INT0 | LDX_FLAG_DPRIME_INT0
+};
+constexpr double kBig32 = 1.024e7;
 
-__device__ inline ldx_ld32 round_pair(const LdRaw &r)
+template <typename Cell>
+__device__ __forceinline__ Cell encode_cell(double kr, double kd, bool r_int0, bool d_int0);
+
+template <>
+__device__ __forceinline__ ldx_ld32 encode_cell<ldx_ld32>(double kr, double kd, bool r_int0, bool d_int0)
 {
     ldx_ld32 o;
-    o.r_square = encode32(round4_k(r.rsq), (r.flags & LDX_FLAG_RSQ_INT0) != 0);
-    o.d_prime = encode32(round4_k(r.dprime), (r.flags & LDX_FLAG_DPRIME_INT0) != 0);
+    o.r_square = r_int0 ? -0.0f : (kr < kBig32 ? (float)(kr * 1e-4) : __uint_as_float(LDX_LD32_BIG_BITS));
+    o.d_prime = d_int0 ? -0.0f : (kd < kBig32 ? (float)(kd * 1e-4) : __uint_as_float(LDX_LD32_BIG_BITS));
     return o;
 }
 
-// The mirror as one out-of-line call: the fallback of ld_pair_fast (rare) must not be inlined 16-128 times.
-static __device__ __noinline__ ldx_ld32 ld_pair_mirror(double f11, double fa1, double fr1, double q1, double fa2,
-                                                       double fr2)
+template <>
+__device__ __forceinline__ ldx_k16 encode_cell<ldx_k16>(double kr, double kd, bool r_int0, bool d_int0)
+{
+    ldx_k16 o;
+    o.r_square = r_int0 ? (uint16_t)LDX_K16_INT0 : (kr < 32767.0 ? (uint16_t)(uint32_t)kr : (uint16_t)LDX_K16_BIG);
+    o.d_prime = d_int0 ? (uint16_t)LDX_K16_INT0 : (kd < 32767.0 ? (uint16_t)(uint32_t)kd : (uint16_t)LDX_K16_BIG);
+    return o;
+}
+
+template <typename Cell>
+__device__ __forceinline__ Cell zero_cell();   // a cell outside the triangle (row <= col, pad rows): the template's 0
+template <>
+__device__ __forceinline__ ldx_ld32 zero_cell<ldx_ld32>() { return ldx_ld32{0.0f, 0.0f}; }
+template <>
+__device__ __forceinline__ ldx_k16 zero_cell<ldx_k16>() { return ldx_k16{0, 0}; }
+
+template <typename Cell>
+__device__ __forceinline__ Cell encode_cell(const LdK &k)
+{
+    return encode_cell<Cell>(k.kr, k.kd, (k.flags & LDX_FLAG_RSQ_INT0) != 0, (k.flags & LDX_FLAG_DPRIME_INT0) != 0);
+}
+
+__device__ inline LdK round_pair(const LdRaw &r)
+{
+    return LdK{round4_k(r.rsq), round4_k(r.dprime), r.flags};
+}
+
+// The mirror as one out-of-line call: the fallback of the fast epilogues (rare) must not be inlined 16-128 times.
+static __device__ __noinline__ LdK ld_pair_mirror(double f11, double fa1, double fr1, double q1, double fa2, double fr2)
 {
     return round_pair(ld_epilogue(f11, fa1, fr1, q1, fa2, fr2));
 }
@@ -150,8 +186,8 @@ __device__ __forceinline__ double div_by_n(double c, double n, double rn)
 //     the same integer unless y is within 1e-6 of a half-integer (or absurdly large): only then `slow` is
 //     set and the caller recomputes that pair with ld_pair_mirror.  Exact ties (e.g. D' = 27/32) always
 //     take the slow path, so the reference's tie behaviour (decided by its own rounding errors) is kept.
-__device__ __forceinline__ ldx_ld32 ld_pair_fast(double f11, double fa1, double fr1, double q1, double fa2,
-                                                 double fr2, bool &slow)
+__device__ __forceinline__ LdK ld_pair_fast(double f11, double fa1, double fr1, double q1, double fa2,
+                                            double fr2, bool &slow)
 {
     const double p = fa1 * fa2;
     const double d = f11 - p;
@@ -174,10 +210,11 @@ __device__ __forceinline__ ldx_ld32 ld_pair_fast(double f11, double fa1, double 
     const bool sure = __builtin_fabs(yd - kd) < 0.499999 && __builtin_fabs(yr - kr) < 0.499999 &&
                       __builtin_fmax(yd, yr) < 1e9;
     slow = !(sure || degenerate);
-    ldx_ld32 o;
-    const float vd = (float)(kd * 1e-4), vr = (float)(kr * 1e-4);   // float32 nearest to k / 10^4
-    o.d_prime = degenerate ? -0.0f : vd;
-    o.r_square = (degenerate || d == 0.0) ? -0.0f : vr;      // d_prime == 0 <=> d == 0 when bound != 0
+    LdK o;
+    o.kr = kr;
+    o.kd = kd;
+    // d_prime == 0 <=> d == 0 when bound != 0
+    o.flags = (degenerate ? LDX_FLAG_DPRIME_INT0 : 0u) | ((degenerate || d == 0.0) ? LDX_FLAG_RSQ_INT0 : 0u);
     return o;
 }
 
@@ -254,33 +291,6 @@ __device__ __forceinline__ FastCol fast_col(double fa, double fr, double n)
     return o;
 }
 
-// cnt_scaled = count_scale * n11 as a double
-__device__ __forceinline__ ldx_ld32 ld_pair_fast2(double cnt_scaled, const FastConst &k, double a1s, double ra1,
-                                                  double rr1, double rq1s, double a2, double ra2, double rr2,
-                                                  double rq2, bool &slow)
-{
-    const double dn4 = __builtin_fma(cnt_scaled, k.nsc, -(a1s * a2));   // 1e4 * Dn, exact (< 2^53)
-    const bool neg = dn4 < 0.0;
-    const double x = neg ? ra2 : rr2, y = neg ? rr2 : ra2;
-    const double inv = max_raw(ra1 * x, rr1 * y);                        // 1 / B  (inf: degenerate)
-    const double yd = __builtin_fabs(dn4) * inv;                         // D'  * 10^4
-    const double z = dn4 * (rq1s * rq2);
-    const double yr = z * dn4;                                           // r^2 * 10^4
-    const double kd = __builtin_rint(yd), kr = __builtin_rint(yr);
-    const double hd = __builtin_fma(inv, k.ncd, 0.499999);
-    const double hr = __builtin_fma(__builtin_fabs(z), k.ncr, 0.499999);
-    // `&`, not `&&`: a short-circuit becomes a branch per pair and the pairs' chains no longer interleave
-    const bool sure = (__builtin_fabs(yd - kd) < hd) & (__builtin_fabs(yr - kr) < hr) & (max_raw(yd, yr) < 1e7) &
-                      (dn4 != 0.0);
-    const bool degenerate = inv == __builtin_inf();
-    slow = !(sure || degenerate);
-    ldx_ld32 o;
-    const float vd = (float)(kd * 1e-4), vr = (float)(kr * 1e-4);        // float32 nearest to k / 10^4
-    o.d_prime = degenerate ? -0.0f : vd;
-    o.r_square = degenerate ? -0.0f : vr;
-    return o;
-}
-
 // W pairs at once, stage by stage: ld_pair_fast2 for the operand sets (r[k], c[k]), k < W, with the W dependent
 // chains INTERLEAVED by construction.  Left to itself hipcc schedules each pair's ~36 instructions back to back
 // (register pressure beside 128 live accumulators), every fp64 instruction then waits for its predecessor's
@@ -293,10 +303,11 @@ __device__ __forceinline__ ldx_ld32 ld_pair_fast2(double cnt_scaled, const FastC
 // kClean: the caller has established that no operand is degenerate (every count > 0) and that no SNP has missing
 // codes (a + r == n, hence D' <= 1 and r^2 <= 1 up to rounding): the inf test, the int-0 selects and the y < 1e7
 // guard are dropped.
-// T = int (the int8 matrix kernel's accumulators, 8 * n11) or float (the FP4 kernel's, n11: exact integers < 2^24)
-template <int W, bool kClean = false, typename T = int>
+// T = int (the int8 matrix kernel's accumulators, 8 * n11) or float (the FP4 kernel's, n11: exact integers < 2^24);
+// Cell = ldx_ld32 or ldx_k16 (the last stage encodes k for it)
+template <int W, bool kClean, typename Cell, typename T>
 __device__ __forceinline__ void ld_multi_fast2(const T (&cnt_scaled)[W], const FastConst &k, const FastRow (&r)[W],
-                                               const FastCol (&c)[W], ldx_ld32 (&out)[W], bool (&slow)[W])
+                                               const FastCol (&c)[W], Cell (&out)[W], bool (&slow)[W])
 {
     double dn4[W], x[W], y[W], inv[W], w[W], z[W], yd[W], yr[W], kd[W], kr[W], hd[W], hr[W], ed[W], er[W], mx[W];
     bool ok[W], deg[W];
@@ -310,14 +321,25 @@ __device__ __forceinline__ void ld_multi_fast2(const T (&cnt_scaled)[W], const F
               hr[t_] = __builtin_fma(__builtin_fabs(z[t_]), k.ncr, 0.499999))
     LDX_STAGE(kd[t_] = __builtin_rint(yd[t_]); hd[t_] = __builtin_fma(inv[t_], k.ncd, 0.499999); er[t_] = yr[t_] - kr[t_];
               if (!kClean) mx[t_] = max_raw(yd[t_], yr[t_]))
+    constexpr bool kF32 = std::is_same<Cell, ldx_ld32>::value;
     LDX_STAGE(ed[t_] = yd[t_] - kd[t_]; ok[t_] = (__builtin_fabs(er[t_]) < hr[t_]) & (dn4[t_] != 0.0);
               if (!kClean) { ok[t_] = ok[t_] & (mx[t_] < 1e7); deg[t_] = inv[t_] == __builtin_inf(); }
-              kr[t_] = kr[t_] * 1e-4)
-    LDX_STAGE(ok[t_] = ok[t_] & (__builtin_fabs(ed[t_]) < hd[t_]); kd[t_] = kd[t_] * 1e-4)
-    LDX_STAGE(const float vr = (float)kr[t_]; const float vd = (float)kd[t_];   // float32 nearest to k / 10^4
-              if (kClean) { out[t_].r_square = vr; out[t_].d_prime = vd; slow[t_] = !ok[t_]; }
-              else { out[t_].r_square = deg[t_] ? -0.0f : vr; out[t_].d_prime = deg[t_] ? -0.0f : vd;
-                     slow[t_] = !(ok[t_] | deg[t_]); })
+              if (kF32) kr[t_] = kr[t_] * 1e-4)
+    LDX_STAGE(ok[t_] = ok[t_] & (__builtin_fabs(ed[t_]) < hd[t_]); if (kF32) kd[t_] = kd[t_] * 1e-4)
+    if constexpr (kF32) {
+        LDX_STAGE(const float vr = (float)kr[t_]; const float vd = (float)kd[t_];   // float32 nearest to k / 10^4 (k < 10^7 here)
+                  if (kClean) { out[t_].r_square = vr; out[t_].d_prime = vd; slow[t_] = !ok[t_]; }
+                  else { out[t_].r_square = deg[t_] ? -0.0f : vr; out[t_].d_prime = deg[t_] ? -0.0f : vd;
+                         slow[t_] = !(ok[t_] | deg[t_]); })
+    } else {   // k itself: 15 bits each; a sure k >= 32767 (only with missing codes) goes to the caller's slow path, whose
+               // encoder writes the escape
+        LDX_STAGE(const uint32_t ur = (uint32_t)kr[t_]; const uint32_t ud = (uint32_t)kd[t_];
+                  if (kClean) { out[t_].r_square = (uint16_t)ur; out[t_].d_prime = (uint16_t)ud; slow[t_] = !ok[t_]; }
+                  else { const bool fits = (ur | ud) < 32767u;
+                         out[t_].r_square = deg[t_] ? (uint16_t)LDX_K16_INT0 : (uint16_t)ur;
+                         out[t_].d_prime = deg[t_] ? (uint16_t)LDX_K16_INT0 : (uint16_t)ud;
+                         slow[t_] = !((ok[t_] & fits) | deg[t_]); })
+    }
 }
 #undef LDX_STAGE
 

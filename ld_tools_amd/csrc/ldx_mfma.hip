@@ -207,11 +207,11 @@ constexpr uint32_t kStatRows = kRows64;
 // v_mfma_i32_32x32x32_i8: a K-block is then 256 haplotypes -- two 128-haplotype chunks, one per lane half -- in four
 // steps of 64, so the loop below keeps its shape (per step 8 MFMAs, 4 fragment reads, one quarter of the thread's share
 // of a later block's j-tile image) with `nblocks` = nchunks / 2 iterations and ~16 instead of ~28 VALU per step.
-template <bool kRaw, bool kN11, bool kArea = false, bool kFp4 = false>
+template <bool kRaw, bool kN11, bool kArea = false, bool kFp4 = false, typename Cell = ldx_ld32>
 __global__ void __launch_bounds__(kMfmaThreads, kArea ? 2 : kWgPerCu)
 triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ fa, const double *__restrict__ fr,
                      const double *__restrict__ q, uint32_t n_snps, uint32_t n_slabs, uint32_t nchunks, double n,
-                     double rn, uint64_t u_begin, uint64_t u_end, ldx_ld32 *__restrict__ out, ldx_ld64 *__restrict__ raw,
+                     double rn, uint64_t u_begin, uint64_t u_end, Cell *__restrict__ out, ldx_ld64 *__restrict__ raw,
                      uint32_t *__restrict__ n11, uint32_t p_begin, uint32_t p_end_arg, uint32_t n_short, uint32_t *sched,
                      int ablate_arg, unsigned long long *stamps, AreaArgs aa)
 {
@@ -489,6 +489,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
             }
             __syncthreads();
             LDX_STAMP(1);
+            if (ablate & 32) __builtin_amdgcn_s_setprio(2);   // tuning: the K-loop wave outranks the epilogue wave instead
             v4i af0[MM], bf0[4], af1[MM], bf1[4];
             read_bf(bf0, bexp, 0);
 #pragma unroll
@@ -582,7 +583,8 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
             if (tid == 0) next_ticket = draw();
             // The epilogue wave outranks the SIMD's other wave (in its K loop, matrix-pipe-bound with issue slots
             // to spare) in instruction arbitration: +2 % at 40k SNPs.
-            if (!(ablate & 16)) __builtin_amdgcn_s_setprio(3);
+            if (ablate & 32) __builtin_amdgcn_s_setprio(0);
+            else if (!(ablate & 16)) __builtin_amdgcn_s_setprio(3);
             if (!active) {   // wave-uniform; inactive waves only helped with B and the barriers
                 if (tid == 0) tickets[parity] = next_ticket;
                 return;
@@ -623,7 +625,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 uint32_t ri[MM], cnt[MM][4];
                 uint64_t us[MM];
                 bool in_range[MM], valid[MM][4], slow[MM][4];
-                ldx_ld32 res[MM][4];
+                Cell res[MM][4];
                 ldx_ld64 rw[MM][4];
                 bool any_slow = false;
 #pragma unroll
@@ -643,7 +645,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                             valid[m][tt] = (i > j) && (i < n_snps);
                             cnt[m][tt] = count_of(acc[m][tt][e]);
                             const LdRaw lr = ld_epilogue((double)cnt[m][tt] / n, fa1, fr1, q1, fa2[tt], fr2[tt]);   // calc_ld.py:33
-                            res[m][tt] = round_pair(lr);
+                            res[m][tt] = encode_cell<Cell>(round_pair(lr));
                             rw[m][tt] = valid[m][tt] ? ldx_ld64{lr.rsq, lr.dprime} : ldx_ld64{0.0, 0.0};
                         }
                     }
@@ -679,7 +681,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                         }
                         FastRow frk[2];
                         accel_t a8[2];
-                        ldx_ld32 r2[2];
+                        Cell r2[2];
                         bool s2[2];
 #pragma unroll
                         for (int k = 0; k < 2; ++k) {
@@ -692,11 +694,11 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                         if (ablate & 1) {   // tuning: no epilogue arithmetic
 #pragma unroll
                             for (int k = 0; k < 2; ++k) {
-                                res[chain_m(pp, k)][chain_tt(pp, k)] = ldx_ld32{(float)a8[k], 0.0f};
+                                res[chain_m(pp, k)][chain_tt(pp, k)] = encode_cell<Cell>((double)a8[k], 0.0, false, false);
                                 slow[chain_m(pp, k)][chain_tt(pp, k)] = false;
                             }
                         } else {
-                            ld_multi_fast2<2, kClean>(a8, fk, frk, fcx, r2, s2);
+                            ld_multi_fast2<2, kClean, Cell>(a8, fk, frk, fcx, r2, s2);
 #pragma unroll
                             for (int k = 0; k < 2; ++k) {
                                 const int m = chain_m(pp, k), tt = chain_tt(pp, k);
@@ -713,7 +715,8 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                             for (int tt = 0; tt < 4; ++tt)
                                 if (slow[m][tt]) {
                                     const uint32_t i = row0 + ri[m], j = t * kSlab + 32u * tt + l32;
-                                    res[m][tt] = ld_pair_mirror((double)count_of(acc[m][tt][e]) / n, fa[i], fr[i], q[i], fa[j], fr[j]);
+                                    res[m][tt] = encode_cell<Cell>(
+                                        ld_pair_mirror((double)count_of(acc[m][tt][e]) / n, fa[i], fr[i], q[i], fa[j], fr[j]));
                                 }
                     }
                 }
@@ -724,8 +727,8 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                         for (int tt = 0; tt < 4; ++tt) {
                             const uint32_t jl = 32u * tt + l32;
                             const size_t o = (size_t)(us[m] - u_begin) * LDX_UNIT_PAIRS + (size_t)((ri[m] + roff) % kGroup) * kSlab + jl;
-                            ldx_ld32 w = res[m][tt];
-                            if (!kClean && !valid[m][tt]) w = ldx_ld32{0.0f, 0.0f};
+                            Cell w = res[m][tt];
+                            if (!kClean && !valid[m][tt]) w = zero_cell<Cell>();
                             out[o] = w;
                             if (kRaw) raw[o] = rw[m][tt];
                             if (kN11) n11[o] = valid[m][tt] ? count_of(acc[m][tt][e]) : 0u;
@@ -744,7 +747,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
             auto area_epilogue = [&]() {
               if constexpr (kArea && MM == 2) {
                 uint64_t slot = hit_slot, slot_end = hit_slot_end;
-                const float kthr = (float)aa.k_thres;
+                const double kthr = aa.k_thres;
                 const bool prefilter = aa.k_thres > 2.0;
                 const double kcand = aa.k_thres - 2.0;
                 auto append = [&](bool keep, uint32_t qrow, uint32_t orow, ldx_ld32 v) {
@@ -815,7 +818,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                             }
                             if (!__any(cand)) continue;   // wave-uniform: nothing near the threshold in these 128 pairs
                         }
-                        ld_multi_fast2<2, false>(a8, fk, frx, fcx, r2, s2);
+                        ld_multi_fast2<2, false, ldx_ld32>(a8, fk, frx, fcx, r2, s2);
 #pragma unroll
                         for (int m = 0; m < 2; ++m) {
                             const uint32_t i = row0 + ri[m];
@@ -830,13 +833,16 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                             if (__builtin_expect(__any(s2[m] && (in_a || in_b)), 0)) {
                                 if (s2[m] && (in_a || in_b)) {
                                     const double f11 = (double)count_of(a8[m]) / n;
-                                    ra = ld_pair_mirror(f11, fa[i], fr[i], q[i], fa[j], fr[j]);
-                                    rb = ld_pair_mirror(f11, fa[j], fr[j], q[j], fa[i], fr[i]);
+                                    ra = encode_cell<ldx_ld32>(ld_pair_mirror(f11, fa[i], fr[i], q[i], fa[j], fr[j]));
+                                    rb = encode_cell<ldx_ld32>(ld_pair_mirror(f11, fa[j], fr[j], q[j], fa[i], fr[i]));
                                 }
                             }
-                            // rounded value * 10^4 back as an integer (exact for values < 1024; -0.0f = int 0 -> 0)
-                            const float ka = __builtin_rintf((aa.measure == LDX_MEASURE_RSQ ? ra.r_square : ra.d_prime) * 1e4f);
-                            const float kb = __builtin_rintf((aa.measure == LDX_MEASURE_RSQ ? rb.r_square : rb.d_prime) * 1e4f);
+                            // rounded value * 10^4 back as an integer (exact for values < 1024; -0.0f = int 0 -> 0; the
+                            // escape NaN of a value >= 1024 counts as +inf: it passes every threshold the band accepts)
+                            const float va = aa.measure == LDX_MEASURE_RSQ ? ra.r_square : ra.d_prime;
+                            const float vb = aa.measure == LDX_MEASURE_RSQ ? rb.r_square : rb.d_prime;
+                            const double ka = va != va ? __builtin_inf() : __builtin_rint((double)va * 1e4);
+                            const double kb = vb != vb ? __builtin_inf() : __builtin_rint((double)vb * 1e4);
                             append(in_a && ka >= kthr, i, j, ra);                              // ld_area.py:248
                             append(in_b && kb >= kthr, j, i, rb);
                         }
@@ -937,9 +943,9 @@ static int acquire_sched(hipStream_t s, uint32_t **sched)
     return LDX_OK;
 }
 
-template <bool kRaw, bool kN11, bool kFp4>
+template <bool kRaw, bool kN11, bool kFp4, typename Cell>
 static int launch_mfma(const void *alt, const double *fa, const double *fr, const double *q, uint32_t n_snps,
-                       uint32_t n_hap, uint64_t unit_begin, uint64_t unit_end, ldx_ld32 *out, ldx_ld64 *out_raw,
+                       uint32_t n_hap, uint64_t unit_begin, uint64_t unit_end, Cell *out, ldx_ld64 *out_raw,
                        uint32_t *out_n11, hipStream_t s)
 {
     const uint32_t nch = n_chunks(n_hap);
@@ -989,7 +995,7 @@ static int launch_mfma(const void *alt, const double *fa, const double *fr, cons
         LDX_HIP(hipMemsetAsync(stamps, 0, stamp_words * 8, s));
     }
 #endif
-    triangle_mfma_kernel<kRaw, kN11, false, kFp4><<<(uint32_t)grid, kMfmaThreads, lds, s>>>(
+    triangle_mfma_kernel<kRaw, kN11, false, kFp4, Cell><<<(uint32_t)grid, kMfmaThreads, lds, s>>>(
         (const uint4 *)alt, fa, fr, q, n_snps, n_slabs(n_snps), nch, (double)n_hap, 1.0 / (double)n_hap, unit_begin,
         unit_end, out, out_raw, out_n11, p_begin, p_end, n_short, sched, ablate, stamps, AreaArgs{});
     LDX_HIP(hipGetLastError());
@@ -1012,16 +1018,22 @@ static int launch_mfma(const void *alt, const double *fa, const double *fr, cons
 }
 
 int triangle_mfma(const void *alt, const double *fa, const double *fr, const double *q, uint32_t n_snps, uint32_t n_hap,
-                  uint64_t unit_begin, uint64_t unit_end, ldx_ld32 *out, ldx_ld64 *out_raw, uint32_t *out_n11, bool fp4,
-                  hipStream_t s)
+                  uint64_t unit_begin, uint64_t unit_end, int out_format, void *out, ldx_ld64 *out_raw, uint32_t *out_n11,
+                  bool fp4, hipStream_t s)
 {
-#define LDX_GO(R, N)                                                                                                    \
-    return fp4 ? launch_mfma<R, N, true>(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end, out, out_raw, out_n11, s) \
-               : launch_mfma<R, N, false>(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end, out, out_raw, out_n11, s)
-    if (out_raw && out_n11) LDX_GO(true, true);
-    if (out_raw) LDX_GO(true, false);
-    if (out_n11) LDX_GO(false, true);
-    LDX_GO(false, false);
+#define LDX_GO(R, N, CELL)                                                                                          \
+    return fp4 ? launch_mfma<R, N, true, CELL>(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end, (CELL *)out,    \
+                                               out_raw, out_n11, s)                                                 \
+               : launch_mfma<R, N, false, CELL>(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end, (CELL *)out,   \
+                                                out_raw, out_n11, s)
+    if (out_format == LDX_OUT_K16) {   // no unrounded output beside the 4-byte cells (ldx_triangle_ex_dev checks)
+        if (out_n11) LDX_GO(false, true, ldx_k16);
+        LDX_GO(false, false, ldx_k16);
+    }
+    if (out_raw && out_n11) LDX_GO(true, true, ldx_ld32);
+    if (out_raw) LDX_GO(true, false, ldx_ld32);
+    if (out_n11) LDX_GO(false, true, ldx_ld32);
+    LDX_GO(false, false, ldx_ld32);
 #undef LDX_GO
 }
 
@@ -1116,12 +1128,12 @@ int area_mfma(const void *alt, const double *fa, const double *fr, const double 
     const uint64_t units = ldx_triangle_units(n_snps) / 8u;   // 64-row units of the full triangle
     if (fp4)
         triangle_mfma_kernel<false, false, true, true><<<(uint32_t)cus * 2u, kMfmaThreads, lds, s>>>(
-            (const uint4 *)alt, fa, fr, q, n_snps, T, nch, (double)n_hap, 1.0 / (double)n_hap, 0, units * 8u, nullptr,
-            nullptr, nullptr, 0u, 0u, 0u, sched, 0, nullptr, aa);
+            (const uint4 *)alt, fa, fr, q, n_snps, T, nch, (double)n_hap, 1.0 / (double)n_hap, 0, units * 8u,
+            (ldx_ld32 *)nullptr, nullptr, nullptr, 0u, 0u, 0u, sched, 0, nullptr, aa);
     else
         triangle_mfma_kernel<false, false, true, false><<<(uint32_t)cus * 2u, kMfmaThreads, lds, s>>>(
-            (const uint4 *)alt, fa, fr, q, n_snps, T, nch, (double)n_hap, 1.0 / (double)n_hap, 0, units * 8u, nullptr,
-            nullptr, nullptr, 0u, 0u, 0u, sched, 0, nullptr, aa);
+            (const uint4 *)alt, fa, fr, q, n_snps, T, nch, (double)n_hap, 1.0 / (double)n_hap, 0, units * 8u,
+            (ldx_ld32 *)nullptr, nullptr, nullptr, 0u, 0u, 0u, sched, 0, nullptr, aa);
     LDX_HIP(hipGetLastError());
     return LDX_OK;
 }

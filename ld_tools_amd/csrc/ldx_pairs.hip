@@ -31,11 +31,11 @@ __device__ inline uint32_t find_tile(uint64_t u, uint64_t G, uint32_t T)
     return lo;
 }
 
-template <bool kRaw, bool kN11>
+template <bool kRaw, bool kN11, typename Cell>
 __global__ void __launch_bounds__(kThreads)
 triangle_kernel(const uint4 *__restrict__ alt, const double *__restrict__ fa, const double *__restrict__ fr,
                 const double *__restrict__ q, uint32_t n_snps, uint32_t n_slabs, uint32_t nchunks, double n,
-                double rn, uint64_t u_begin, uint64_t u_end, ldx_ld32 *__restrict__ out, ldx_ld64 *__restrict__ raw,
+                double rn, uint64_t u_begin, uint64_t u_end, Cell *__restrict__ out, ldx_ld64 *__restrict__ raw,
                 uint32_t *__restrict__ n11)
 {
     extern __shared__ uint4 lds[];
@@ -81,21 +81,23 @@ triangle_kernel(const uint4 *__restrict__ alt, const double *__restrict__ fa, co
                     const uint32_t j = jj ? j1 : j0;
                     const bool valid = (i > j) && (i < n_snps);   // ld_triangle.py:149-150
                     const size_t o = obase + (size_t)r * kSlab + jj * 64u + lane;
-                    ldx_ld32 res = {0.0f, 0.0f};
+                    Cell res = zero_cell<Cell>();
                     ldx_ld64 rw = {0.0, 0.0};
                     if (valid) {
                         const double f11 = div_by_n((double)acc.v[r][jj], n, rn);   // calc_ld.py:33
+                        LdK lk;
                         if (kRaw) {   // parity / debugging output: the op-for-op mirror, unrounded values kept
                             const LdRaw lr = ld_epilogue(f11, fa1, fr1, q1, fa2[jj], fr2[jj]);
-                            res = round_pair(lr);
+                            lk = round_pair(lr);
                             rw.r_square = lr.rsq;
                             rw.d_prime = lr.dprime;
                         } else {
                             bool slow;
-                            res = ld_pair_fast(f11, fa1, fr1, q1, fa2[jj], fr2[jj], slow);
+                            lk = ld_pair_fast(f11, fa1, fr1, q1, fa2[jj], fr2[jj], slow);
                             if (__builtin_expect(__any(slow), 0))
-                                if (slow) res = ld_pair_mirror(f11, fa1, fr1, q1, fa2[jj], fr2[jj]);
+                                if (slow) lk = ld_pair_mirror(f11, fa1, fr1, q1, fa2[jj], fr2[jj]);
                         }
+                        res = encode_cell<Cell>(lk);
                     }
                     out[o] = res;
                     if (kRaw) raw[o] = rw;
@@ -139,52 +141,164 @@ pair_counts_kernel(const uint4 *__restrict__ alt_i, const uint4 *__restrict__ al
 }
 
 // ---- the epilogue alone, one element per thread ----
+template <typename Cell>
+__device__ inline bool same_cell(const Cell &a, const Cell &b);
+template <>
+__device__ inline bool same_cell<ldx_ld32>(const ldx_ld32 &a, const ldx_ld32 &b)
+{
+    return __float_as_uint(a.r_square) == __float_as_uint(b.r_square) && __float_as_uint(a.d_prime) == __float_as_uint(b.d_prime);
+}
+template <>
+__device__ inline bool same_cell<ldx_k16>(const ldx_k16 &a, const ldx_k16 &b)
+{
+    return a.r_square == b.r_square && a.d_prime == b.d_prime;
+}
+
+// Every production epilogue on the same tuple, for one cell format: the reciprocal-based one of the popcount kernels,
+// the count-domain fp64 one of the matrix kernels (general variant, and the "clean" variant where it applies; int and
+// float count operands), each with its mirror fallback.  They must agree bit for bit; otherwise the result is poisoned.
+template <typename Cell>
+__device__ inline Cell all_tiers(double n, double rn, uint32_t c11, double fa1, double fr1, double fa2, double fr2, bool &same)
+{
+    const double f11 = div_by_n((double)c11, n, rn);
+    const double q1 = fa1 * fr1;
+    bool slow;
+    LdK lk = ld_pair_fast(f11, fa1, fr1, q1, fa2, fr2, slow);
+    if (slow) lk = ld_pair_mirror(f11, fa1, fr1, q1, fa2, fr2);
+    const Cell res = encode_cell<Cell>(lk);
+    const Cell mir = encode_cell<Cell>(ld_pair_mirror(f11, fa1, fr1, q1, fa2, fr2));
+    same = same_cell(res, mir);
+    const FastRow fr_[1] = {fast_row(fa1, fr1, n)};
+    const FastCol fc_[1] = {fast_col(fa2, fr2, n)};
+    const bool ordinary = fast_ordinary(fa1, fr1, n) && fast_ordinary(fa2, fr2, n);
+    {
+        const FastConst fk = fast_const(n, 8.0);
+        const int cnt_[1] = {(int)(c11 * 8u)};
+        Cell g_[1];
+        bool sg_[1];
+        ld_multi_fast2<1, false, Cell>(cnt_, fk, fr_, fc_, g_, sg_);
+        if (sg_[0]) g_[0] = mir;
+        same = same && same_cell(g_[0], res);
+        if (ordinary) {
+            ld_multi_fast2<1, true, Cell>(cnt_, fk, fr_, fc_, g_, sg_);
+            if (sg_[0]) g_[0] = mir;
+            same = same && same_cell(g_[0], res);
+        }
+    }
+    {
+        const FastConst fk = fast_const(n, 1.0);
+        const float cnt_[1] = {(float)c11};
+        Cell g_[1];
+        bool sg_[1];
+        ld_multi_fast2<1, false, Cell>(cnt_, fk, fr_, fc_, g_, sg_);
+        if (sg_[0]) g_[0] = mir;
+        same = same && same_cell(g_[0], res);
+        if (ordinary) {
+            ld_multi_fast2<1, true, Cell>(cnt_, fk, fr_, fc_, g_, sg_);
+            if (sg_[0]) g_[0] = mir;
+            same = same && same_cell(g_[0], res);
+        }
+    }
+    return res;
+}
+
 __global__ void ld_from_counts_kernel(double n, double rn, size_t m, const uint32_t *__restrict__ n11,
                                       const uint32_t *__restrict__ a1, const uint32_t *__restrict__ r1,
                                       const uint32_t *__restrict__ a2, const uint32_t *__restrict__ r2,
-                                      ldx_ld64 *raw, ldx_ld32 *rounded, uint8_t *flags)
+                                      ldx_ld64 *raw, double *kout, ldx_ld32 *cells32, ldx_k16 *cells16, uint8_t *flags)
 {
     const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= m) return;
     const double fa1 = (double)a1[k] / n, fr1 = (double)r1[k] / n;
     const double fa2 = (double)a2[k] / n, fr2 = (double)r2[k] / n;
-    // `raw` and `flags` come from the op-for-op mirror, `rounded` from the production path of the pair
-    // kernels (reciprocal division by n, fast epilogue, mirror fallback near ties) -- so the exhaustive
-    // small-n test pins exactly the code that ld_triangle / ld_area run.
-    const double f11 = div_by_n((double)n11[k], n, rn);
+    // `raw`, `k` and `flags` come from the op-for-op mirror with a real division, the cells from the production
+    // paths of the pair kernels -- so the exhaustive small-n test pins exactly the code that ld_triangle / ld_area run.
     const LdRaw lr = ld_epilogue((double)n11[k] / n, fa1, fr1, fa1 * fr1, fa2, fr2);
     if (raw) raw[k] = ldx_ld64{lr.rsq, lr.dprime};
-    if (rounded) {
-        // every production epilogue on the same tuple: the reciprocal-based one of the popcount kernels, the
-        // count-domain one of the MFMA kernel (general variant, and the "clean" variant where it applies); they
-        // must agree bit for bit, otherwise the result is poisoned so that the exhaustive tests fail loudly
-        bool slow;
-        ldx_ld32 res = ld_pair_fast(f11, fa1, fr1, fa1 * fr1, fa2, fr2, slow);
-        if (slow) res = ld_pair_mirror(f11, fa1, fr1, fa1 * fr1, fa2, fr2);
-        const FastConst fk = fast_const(n, 1.0);
-        const FastRow fr_[1] = {fast_row(fa1, fr1, n)};
-        const FastCol fc_[1] = {fast_col(fa2, fr2, n)};
-        const int cnt_[1] = {(int)n11[k]};
-        ldx_ld32 g_[1], c_[1];
-        bool sg_[1], sc_[1];
-        ld_multi_fast2<1, false>(cnt_, fk, fr_, fc_, g_, sg_);
-        if (sg_[0]) g_[0] = ld_pair_mirror(f11, fa1, fr1, fa1 * fr1, fa2, fr2);
-        bool same = __float_as_uint(g_[0].r_square) == __float_as_uint(res.r_square) &&
-                    __float_as_uint(g_[0].d_prime) == __float_as_uint(res.d_prime);
-        if (fast_ordinary(fa1, fr1, n) && fast_ordinary(fa2, fr2, n)) {
-            ld_multi_fast2<1, true>(cnt_, fk, fr_, fc_, c_, sc_);
-            if (sc_[0]) c_[0] = ld_pair_mirror(f11, fa1, fr1, fa1 * fr1, fa2, fr2);
-            same = same && __float_as_uint(c_[0].r_square) == __float_as_uint(res.r_square) &&
-                   __float_as_uint(c_[0].d_prime) == __float_as_uint(res.d_prime);
-        }
+    if (kout) {
+        kout[2 * k] = round4_k(lr.rsq);
+        kout[2 * k + 1] = round4_k(lr.dprime);
+    }
+    if (cells32) {
+        bool same;
+        ldx_ld32 res = all_tiers<ldx_ld32>(n, rn, n11[k], fa1, fr1, fa2, fr2, same);
         if (!same) res = ldx_ld32{__uint_as_float(0x7FC00000u), __uint_as_float(0x7FC00000u)};
-        rounded[k] = res;
+        cells32[k] = res;
+    }
+    if (cells16) {
+        bool same;
+        ldx_k16 res = all_tiers<ldx_k16>(n, rn, n11[k], fa1, fr1, fa2, fr2, same);
+        if (!same) res = ldx_k16{0xFFFFu, 0xFFFFu};
+        cells16[k] = res;
     }
     if (flags) flags[k] = (uint8_t)lr.flags;
 }
 
+// ---- LD of an explicit list of pairs: one wavefront per pair, AND + popcount over the chunks of the two rows, the
+// op-for-op mirror epilogue with real divisions, k = round4 * 10^4 as doubles (exact for any magnitude) ----
+__global__ void __launch_bounds__(256) ld_pairs_kernel(const uint4 *__restrict__ alt, const uint32_t *__restrict__ acnt,
+                                                       const uint32_t *__restrict__ rcnt, uint32_t n_snps,
+                                                       uint32_t nchunks, double n, const uint32_t *__restrict__ rows,
+                                                       const uint32_t *__restrict__ cols, size_t m, double *kout,
+                                                       ldx_ld64 *raw, uint8_t *flags, uint32_t *n11)
+{
+    const size_t p = (size_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    if (p >= m) return;
+    const uint32_t i = rows[p], j = cols[p];
+    if (i >= n_snps || j >= n_snps) {   // out of range: poison, never read outside the plane
+        if (lane == 0) {
+            if (kout) kout[2 * p] = kout[2 * p + 1] = __builtin_nan("");
+            if (raw) raw[p] = ldx_ld64{__builtin_nan(""), __builtin_nan("")};
+            if (flags) flags[p] = 0xFFu;
+            if (n11) n11[p] = 0xFFFFFFFFu;
+        }
+        return;
+    }
+    const uint4 *ri = alt + ((size_t)(i / kSlab) * nchunks) * kSlab + (i % kSlab);
+    const uint4 *rj = alt + ((size_t)(j / kSlab) * nchunks) * kSlab + (j % kSlab);
+    uint32_t c = 0;
+    for (uint32_t ch = lane; ch < nchunks; ch += 64u) {
+        const uint4 a = ri[(size_t)ch * kSlab], b = rj[(size_t)ch * kSlab];
+        c += __builtin_popcount(a.x & b.x) + __builtin_popcount(a.y & b.y) + __builtin_popcount(a.z & b.z) +
+             __builtin_popcount(a.w & b.w);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+    if (lane == 0) {
+        const double fa1 = (double)acnt[i] / n, fr1 = (double)rcnt[i] / n;   // calc_ld.py:41-44
+        const double fa2 = (double)acnt[j] / n, fr2 = (double)rcnt[j] / n;
+        const LdRaw lr = ld_epilogue((double)c / n, fa1, fr1, fa1 * fr1, fa2, fr2);
+        if (kout) {
+            kout[2 * p] = round4_k(lr.rsq);
+            kout[2 * p + 1] = round4_k(lr.dprime);
+        }
+        if (raw) raw[p] = ldx_ld64{lr.rsq, lr.dprime};
+        if (flags) flags[p] = (uint8_t)lr.flags;
+        if (n11) n11[p] = c;
+    }
+}
+
 // ---- strips -> dense ld_two_dim (ld_triangle.py:114,223-230) ----
-__global__ void triangle_dense_kernel(const ldx_ld32 *__restrict__ strips, uint32_t n_snps, uint32_t n_slabs,
+// one value of a cell as the dense float: the float32 nearest to k / 10^4, -0.0f for the int 0, the NaN LDX_LD32_BIG_BITS
+// for an escape; *k receives k (+inf for an escape)
+__device__ inline float dense_value(const ldx_ld32 &c, int measure, double *k)
+{
+    const float v = measure == LDX_MEASURE_RSQ ? c.r_square : c.d_prime;
+    *k = v != v ? __builtin_inf() : __builtin_rint((double)v * 1e4);
+    return v;
+}
+__device__ inline float dense_value(const ldx_k16 &c, int measure, double *k)
+{
+    const uint32_t u = measure == LDX_MEASURE_RSQ ? c.r_square : c.d_prime;
+    if (u & LDX_K16_INT0) { *k = 0.0; return -0.0f; }
+    if (u == LDX_K16_BIG) { *k = __builtin_inf(); return __uint_as_float(LDX_LD32_BIG_BITS); }
+    *k = (double)u;
+    return (float)((double)u * 1e-4);
+}
+
+template <typename Cell>
+__global__ void triangle_dense_kernel(const Cell *__restrict__ strips, uint32_t n_snps, uint32_t n_slabs,
                                       int measure, int has_thres, double k_thres, uint32_t row_begin,
                                       uint32_t row_end, float *__restrict__ dense, size_t ld)
 {
@@ -196,11 +310,13 @@ __global__ void triangle_dense_kernel(const ldx_ld32 *__restrict__ strips, uint3
         const uint64_t G = (uint64_t)n_slabs * kGroupsPerSlab;
         const uint32_t t = j / kSlab, g = i / kGroup;
         const uint64_t u = tile_base(t, G) + (g - t * kGroupsPerSlab);
-        const ldx_ld32 c = strips[u * LDX_UNIT_PAIRS + (i % kGroup) * kSlab + (j % kSlab)];
-        v = measure == LDX_MEASURE_RSQ ? c.r_square : c.d_prime;
+        const Cell c = strips[u * LDX_UNIT_PAIRS + (i % kGroup) * kSlab + (j % kSlab)];
+        double k;
+        v = dense_value(c, measure, &k);
         // ld_triangle.py:223-225 compares the rounded value k/10^4 with the threshold; k_thres is the
-        // smallest k whose k/10^4 is not below it.  Sub-threshold cells keep the template's int 0.
-        if (has_thres && __builtin_rint((double)v * 1e4) < k_thres) v = -0.0f;
+        // smallest k whose k/10^4 is not below it.  Sub-threshold cells keep the template's int 0; an escape cell
+        // stays an escape (its exact value, fetched by the caller, decides).
+        if (has_thres && k < k_thres) v = -0.0f;
     }
     dense[(size_t)(i - row_begin) * ld + j] = v;
 }
@@ -268,20 +384,20 @@ static int ensure_lds(const void *kernel, size_t bytes)
 
 static int num_cus() { return device_cus(); }
 
-template <bool kRaw, bool kN11>
+template <bool kRaw, bool kN11, typename Cell>
 static int launch_triangle(const void *alt, const double *fa, const double *fr, const double *q, uint32_t n_snps,
-                           uint32_t n_hap, uint64_t unit_begin, uint64_t unit_end, ldx_ld32 *out, ldx_ld64 *out_raw,
+                           uint32_t n_hap, uint64_t unit_begin, uint64_t unit_end, Cell *out, ldx_ld64 *out_raw,
                            uint32_t *out_n11, hipStream_t s)
 {
     const uint32_t nch = ldx::n_chunks(n_hap);
     const size_t lds = tile_lds_bytes(nch);
-    int rc = ensure_lds((const void *)triangle_kernel<kRaw, kN11>, lds);
+    int rc = ensure_lds((const void *)triangle_kernel<kRaw, kN11, Cell>, lds);
     if (rc) return rc;
     const uint64_t total = unit_end - unit_begin;
     uint64_t grid = (uint64_t)num_cus();   // persistent: one 16-wave workgroup per CU
     const uint64_t max_grid = (total + kWaves - 1) / kWaves;   // at least one unit per wave
     if (grid > max_grid) grid = max_grid;
-    triangle_kernel<kRaw, kN11><<<(uint32_t)grid, kThreads, lds, s>>>(
+    triangle_kernel<kRaw, kN11, Cell><<<(uint32_t)grid, kThreads, lds, s>>>(
         (const uint4 *)alt, fa, fr, q, n_snps, ldx::n_slabs(n_snps), nch, (double)n_hap, 1.0 / (double)n_hap, unit_begin,
         unit_end, out, out_raw, out_n11);
     LDX_HIP(hipGetLastError());
@@ -292,16 +408,18 @@ extern "C" int ldx_triangle_dev(const void *alt, const double *fa, const double 
                                 uint32_t n_snps, uint32_t n_hap, uint64_t unit_begin, uint64_t unit_end,
                                 ldx_ld32 *out, ldx_ld64 *out_raw, uint32_t *out_n11, void *stream)
 {
-    return ldx_triangle_path_dev(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end, out, out_raw, out_n11,
-                                 g_triangle_path.load(std::memory_order_relaxed), stream);
+    return ldx_triangle_ex_dev(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end,
+                               g_triangle_path.load(std::memory_order_relaxed), LDX_OUT_LD32, out, out_raw, out_n11, stream);
 }
 
-extern "C" int ldx_triangle_path_dev(const void *alt, const double *fa, const double *fr, const double *q,
-                                     uint32_t n_snps, uint32_t n_hap, uint64_t unit_begin, uint64_t unit_end,
-                                     ldx_ld32 *out, ldx_ld64 *out_raw, uint32_t *out_n11, int path, void *stream)
+extern "C" int ldx_triangle_ex_dev(const void *alt, const double *fa, const double *fr, const double *q,
+                                   uint32_t n_snps, uint32_t n_hap, uint64_t unit_begin, uint64_t unit_end, int path,
+                                   int out_format, void *out, ldx_ld64 *out_raw, uint32_t *out_n11, void *stream)
 {
     LDX_REQUIRE(alt && fa && fr && q && out, "null pointer");
     LDX_REQUIRE(known_path(path), "unknown path");
+    LDX_REQUIRE(out_format == LDX_OUT_LD32 || out_format == LDX_OUT_K16, "unknown output format");
+    LDX_REQUIRE(out_format == LDX_OUT_LD32 || !out_raw, "out_raw needs LDX_OUT_LD32");
     LDX_REQUIRE(n_snps >= 1 && n_hap >= 1, "bad shape");
     if (n_hap > LDX_MAX_HAPS) {
         set_error("ldx_triangle_dev: n_hap %u > LDX_MAX_HAPS %u", n_hap, LDX_MAX_HAPS);
@@ -316,15 +434,22 @@ extern "C" int ldx_triangle_path_dev(const void *alt, const double *fa, const do
     if (unit_begin >= unit_end) return LDX_OK;
     hipStream_t s = (hipStream_t)stream;
     if (path != LDX_PATH_POPCOUNT)   // AUTO = the FP4 matrix kernel (twice the int8 kernel's counting rate)
-        return triangle_mfma(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end, out, out_raw, out_n11,
+        return triangle_mfma(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end, out_format, out, out_raw, out_n11,
                              path != LDX_PATH_MFMA, s);
+    if (out_format == LDX_OUT_K16) {
+        ldx_k16 *o = (ldx_k16 *)out;
+        if (out_n11)
+            return launch_triangle<false, true>(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end, o, out_raw, out_n11, s);
+        return launch_triangle<false, false>(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end, o, out_raw, out_n11, s);
+    }
+    ldx_ld32 *o = (ldx_ld32 *)out;
     if (out_raw && out_n11)
-        return launch_triangle<true, true>(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end, out, out_raw, out_n11, s);
+        return launch_triangle<true, true>(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end, o, out_raw, out_n11, s);
     if (out_raw)
-        return launch_triangle<true, false>(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end, out, out_raw, out_n11, s);
+        return launch_triangle<true, false>(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end, o, out_raw, out_n11, s);
     if (out_n11)
-        return launch_triangle<false, true>(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end, out, out_raw, out_n11, s);
-    return launch_triangle<false, false>(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end, out, out_raw, out_n11, s);
+        return launch_triangle<false, true>(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end, o, out_raw, out_n11, s);
+    return launch_triangle<false, false>(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end, o, out_raw, out_n11, s);
 }
 
 extern "C" int ldx_pair_counts_dev(const void *alt_i, uint32_t n_i, const void *alt_j, uint32_t n_j,
@@ -352,9 +477,9 @@ extern "C" int ldx_pair_counts_dev(const void *alt_i, uint32_t n_i, const void *
     return LDX_OK;
 }
 
-extern "C" int ldx_ld_from_counts_dev(uint32_t n, size_t m, const uint32_t *n11, const uint32_t *a1,
-                                      const uint32_t *r1, const uint32_t *a2, const uint32_t *r2,
-                                      ldx_ld64 *raw, ldx_ld32 *rounded, uint8_t *flags, void *stream)
+extern "C" int ldx_ld_from_counts_ex_dev(uint32_t n, size_t m, const uint32_t *n11, const uint32_t *a1,
+                                         const uint32_t *r1, const uint32_t *a2, const uint32_t *r2, ldx_ld64 *raw,
+                                         double *k, ldx_ld32 *cells32, ldx_k16 *cells16, uint8_t *flags, void *stream)
 {
     LDX_REQUIRE(n11 && a1 && r1 && a2 && r2, "null pointer");
     LDX_REQUIRE(n >= 1, "n must be positive (the reference raises ZeroDivisionError, calc_ld.py:33)");
@@ -364,7 +489,48 @@ extern "C" int ldx_ld_from_counts_dev(uint32_t n, size_t m, const uint32_t *n11,
         return LDX_E_UNSUPPORTED;
     }
     ld_from_counts_kernel<<<(uint32_t)((m + 255) / 256), 256, 0, (hipStream_t)stream>>>(
-        (double)n, 1.0 / (double)n, m, n11, a1, r1, a2, r2, raw, rounded, flags);
+        (double)n, 1.0 / (double)n, m, n11, a1, r1, a2, r2, raw, k, cells32, cells16, flags);
+    LDX_HIP(hipGetLastError());
+    return LDX_OK;
+}
+
+extern "C" int ldx_ld_from_counts_dev(uint32_t n, size_t m, const uint32_t *n11, const uint32_t *a1,
+                                      const uint32_t *r1, const uint32_t *a2, const uint32_t *r2,
+                                      ldx_ld64 *raw, ldx_ld32 *rounded, uint8_t *flags, void *stream)
+{
+    return ldx_ld_from_counts_ex_dev(n, m, n11, a1, r1, a2, r2, raw, nullptr, rounded, nullptr, flags, stream);
+}
+
+extern "C" int ldx_ld_pairs_dev(const void *alt, const uint32_t *acnt, const uint32_t *rcnt, uint32_t n_snps,
+                                uint32_t n_hap, const uint32_t *rows, const uint32_t *cols, size_t m, double *k,
+                                ldx_ld64 *raw, uint8_t *flags, uint32_t *n11, void *stream)
+{
+    LDX_REQUIRE(alt && acnt && rcnt && rows && cols, "null pointer");
+    LDX_REQUIRE(n_snps >= 1 && n_hap >= 1, "bad shape");
+    if (m == 0) return LDX_OK;
+    ld_pairs_kernel<<<(uint32_t)((m + 3) / 4), 256, 0, (hipStream_t)stream>>>(
+        (const uint4 *)alt, acnt, rcnt, n_snps, ldx::n_chunks(n_hap), (double)n_hap, rows, cols, m, k, raw, flags, n11);
+    LDX_HIP(hipGetLastError());
+    return LDX_OK;
+}
+
+extern "C" int ldx_triangle_dense_ex_dev(const void *strips, int strips_format, uint32_t n_snps, int measure,
+                                         int has_thres, double thres, uint32_t row_begin, uint32_t row_end, float *dense,
+                                         size_t ld, void *stream)
+{
+    LDX_REQUIRE(strips && dense, "null pointer");
+    LDX_REQUIRE(strips_format == LDX_OUT_LD32 || strips_format == LDX_OUT_K16, "unknown cell format");
+    LDX_REQUIRE(row_begin <= row_end && row_end <= n_snps && ld >= n_snps, "bad shape");
+    LDX_REQUIRE(measure == LDX_MEASURE_RSQ || measure == LDX_MEASURE_DPRIME, "bad measure");
+    if (row_begin == row_end) return LDX_OK;
+    const dim3 grid((n_snps + 255u) / 256u, row_end - row_begin);
+    const double kt = has_thres ? thres_to_k(thres) : 0.0;
+    if (strips_format == LDX_OUT_K16)
+        triangle_dense_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const ldx_k16 *)strips, n_snps, ldx::n_slabs(n_snps),
+                                                                    measure, has_thres, kt, row_begin, row_end, dense, ld);
+    else
+        triangle_dense_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const ldx_ld32 *)strips, n_snps, ldx::n_slabs(n_snps),
+                                                                    measure, has_thres, kt, row_begin, row_end, dense, ld);
     LDX_HIP(hipGetLastError());
     return LDX_OK;
 }
@@ -373,15 +539,8 @@ extern "C" int ldx_triangle_dense_dev(const ldx_ld32 *strips, uint32_t n_snps, i
                                       double thres, uint32_t row_begin, uint32_t row_end, float *dense, size_t ld,
                                       void *stream)
 {
-    LDX_REQUIRE(strips && dense, "null pointer");
-    LDX_REQUIRE(row_begin <= row_end && row_end <= n_snps && ld >= n_snps, "bad shape");
-    LDX_REQUIRE(measure == LDX_MEASURE_RSQ || measure == LDX_MEASURE_DPRIME, "bad measure");
-    if (row_begin == row_end) return LDX_OK;
-    triangle_dense_kernel<<<dim3((n_snps + 255u) / 256u, row_end - row_begin), 256, 0, (hipStream_t)stream>>>(
-        strips, n_snps, ldx::n_slabs(n_snps), measure, has_thres, has_thres ? thres_to_k(thres) : 0.0, row_begin,
-        row_end, dense, ld);
-    LDX_HIP(hipGetLastError());
-    return LDX_OK;
+    return ldx_triangle_dense_ex_dev(strips, LDX_OUT_LD32, n_snps, measure, has_thres, thres, row_begin, row_end, dense,
+                                     ld, stream);
 }
 
 extern "C" int ldx_probe_andpop_dev(uint32_t *sink, uint32_t blocks, uint32_t threads, uint32_t iters, void *stream)

@@ -12,7 +12,7 @@ import numpy as np
 
 from ..ops import ld_area
 from ..panel import PackedPanel
-from .ingest import codes_matrix, find_record, k_to_python, sample_genotypes
+from .ingest import codes_matrix, find_record, sample_genotypes
 
 HEADER_ROW = ["hg38_pos", "rsID", "ref", "alt", "type", "alt_freq", "r2", "D'", "dist"]   # ld_area.py:97-105
 _RS = re.compile(r"rs\d+$")
@@ -79,7 +79,7 @@ def area_scan(vcf, chrom, chrom_rows: Sequence[Sequence], sample_names: Sequence
     hits = ld_area(panel, positions, uniq_q, flank=flank_size + extra, measure=ld_thres_measure, thres=ld_low_thres)
     hq = hits.query.cpu().numpy()
     ho = hits.oppos.cpu().numpy()
-    hv = hits.ld32.cpu().numpy()
+    hv = hits.python_values(panel)                                   # [(r2, D')] as the reference's Python values
     alt_freq = panel.alt_freq4().cpu().numpy()
     by_query = {}
     for qrow, orow, (r2, dp) in zip(hq.tolist(), ho.tolist(), hv):
@@ -95,8 +95,7 @@ def area_scan(vcf, chrom, chrom_rows: Sequence[Sequence], sample_names: Sequence
                 continue
             if not (positions[orow] - 1 < high and stops[orow] > low):                # pysam overlap with [low, high)
                 continue
-            r2_py, dp_py = k_to_python(np.array([r2, dp], dtype=np.float32))
-            res.hits.append(_ann(o) + [float(alt_freq[orow]), r2_py, dp_py, o.pos - q.pos])
+            res.hits.append(_ann(o) + [float(alt_freq[orow]), r2, dp, o.pos - q.pos])
         results.append(res)
     return results
 

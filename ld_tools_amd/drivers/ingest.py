@@ -54,12 +54,22 @@ def codes_matrix(genotype_rows: Iterable[Sequence]) -> np.ndarray:
     return np.stack(rows).astype(np.int8, copy=False)
 
 
-def k_to_python(values32: np.ndarray):
+def k_to_python(values32: np.ndarray, fixes=None):
     """Device float32 results -> the reference's Python values: float ``k / 10**4`` (== round(x, 4)), or the int 0
-    where the value carries the int-0 mark (-0.0f; calc_ld.py:68-69,75-76,89-90)."""
+    where the value carries the int-0 mark (-0.0f; calc_ld.py:68-69,75-76,89-90).  ``fixes`` maps the index of an
+    escape cell (NaN: a value the float32 cannot identify, >= 1024) -- flat, or (row, col) for a 2-D input -- to its exact
+    Python value (TriangleResult.dense_values / ops.ld_pairs); an escape without a fix is an error, never a guess."""
     v = np.asarray(values32, dtype=np.float32)
-    k = np.rint(v.astype(np.float64) * 1e4)
+    esc = np.isnan(v)
+    k = np.rint(np.where(esc, 0, v).astype(np.float64) * 1e4)
     int0 = np.signbit(v) & (v == 0)
     flat_k, flat_z = k.ravel(), int0.ravel()
     out = [0 if z else kk / 10000.0 for kk, z in zip(flat_k.tolist(), flat_z.tolist())]
+    if esc.any():
+        fixes = fixes or {}
+        for flat in np.flatnonzero(esc.ravel()).tolist():
+            key = flat if v.ndim < 2 else tuple(int(x) for x in np.unravel_index(flat, v.shape))
+            if key not in fixes:
+                raise ValueError(f"escape cell {key} has no exact value: resolve it with ops.ld_pairs")
+            out[flat] = fixes[key]
     return out

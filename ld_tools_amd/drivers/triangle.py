@@ -43,8 +43,8 @@ def triangle_matrix(vcf, chrom, chrom_rows: Sequence[Sequence], sample_names: Se
     panel = PackedPanel.from_codes(codes_matrix(genotypes))
     res = ld_triangle(panel)
     n = len(rows)
-    dense = res.dense(ld_measure, ld_low_thres).cpu().numpy()         # -0.0 = the template's / a computed int 0
-    flat = k_to_python(dense)
+    dense, fixes = res.dense_values(ld_measure, ld_low_thres)        # -0.0 = the template's / a computed int 0
+    flat = k_to_python(dense, fixes)
     ld_two_dim = [flat[r * n:(r + 1) * n] for r in range(n)]
     alt_freqs = panel.alt_freq4().cpu().numpy().tolist()
     return TriangleMatrix(chrom, rs_ids, poss, ld_two_dim, alleles, types, alt_freqs)
@@ -94,15 +94,18 @@ def stream_triangle_table(path: str, chrom: str, rs_ids_srtd: Sequence[str], pos
         out.write("\tPositions\t" + "\t".join(poss) + "\n")
         for r0 in range(0, n, rows_per_block):
             r1 = min(n, r0 + rows_per_block)
-            v = result.dense(ld_measure, ld_low_thres, rows=(r0, r1)).cpu().numpy()
-            k = np.rint(v.astype(np.float64) * 1e4).astype(np.int64)
+            v, fixes = result.dense_values(ld_measure, ld_low_thres, rows=(r0, r1))
+            esc = np.isnan(v)
+            k = np.rint(np.where(esc, 0, v).astype(np.float64) * 1e4).astype(np.int64)
             int0 = np.signbit(v) & (v == 0)
-            big = k > 10000                                   # D' or r^2 above 1: only with missing codes; rare, formatted one by one
+            big = (k > 10000) & ~esc                          # D' or r^2 above 1: only with missing codes; rare, formatted one by one
             idx = np.where(int0, 10001, np.minimum(k, 10000))
             text = table[idx]
             if big.any():
                 for rr, cc in zip(*np.nonzero(big)):
                     text[rr, cc] = str(k[rr, cc] / 10000.0)
+            for (ar, ac), val in fixes.items():               # values the cell format cannot hold: exact, from ld_pairs
+                text[ar - r0, ac] = str(val)
             for row_index in range(r0, r1):
                 out.write(rs_ids_srtd[row_index] + "\t" + poss[row_index] + "\t" + "\t".join(text[row_index - r0]) + "\n")
 

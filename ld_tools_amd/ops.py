@@ -48,14 +48,30 @@ def get_area_path() -> str:
 # --------------------------------------------------------------------------- triangle
 @dataclass
 class TriangleResult:
-    """Strip-packed lower triangle of one panel (layout: include/ldx.h, "Triangle work units")."""
+    """Strip-packed lower triangle of one panel (layout: include/ldx.h, "Triangle work units").
+
+    The cells are in ONE of the two formats of include/ldx.h: ``ld32`` (float32 nearest to k / 10^4, -0.0 = the
+    reference's int 0, 8 bytes per pair) or ``k16`` (k itself in 15 bits + an int-0 bit, 4 bytes per pair).  Values a
+    format cannot hold (>= 1024 / >= 3.2767: only with missing codes) are escape cells; ``exact()`` /
+    ``dense_values()`` resolve them through ldx_ld_pairs_dev, so nothing is ever returned inexact.
+    """
 
     n_snps: int
     unit_begin: int
     unit_end: int
-    ld32: torch.Tensor                       # float32 [(units)*1024, 2]  (r_square, d_prime) rounded to 4 dp
+    ld32: Optional[torch.Tensor] = None      # float32 [(units)*1024, 2]  (r_square, d_prime) rounded to 4 dp
     raw: Optional[torch.Tensor] = None       # float64 [(units)*1024, 2]  unrounded
     n11: Optional[torch.Tensor] = None       # int32   [(units)*1024]     alt/alt haplotype counts
+    k16: Optional[torch.Tensor] = None       # int16   [(units)*1024, 2]  bit patterns of the uint16 cells
+    panel: Optional[PackedPanel] = None      # the panel the result came from (resolves escape cells)
+
+    @property
+    def fmt(self) -> str:
+        return "ld32" if self.ld32 is not None else "k16"
+
+    @property
+    def cells(self) -> torch.Tensor:
+        return self.ld32 if self.ld32 is not None else self.k16
 
     def cell_index(self, rows, cols) -> np.ndarray:
         """Flat element index (relative to this shard) of cells (row > col)."""
@@ -70,51 +86,97 @@ class TriangleResult:
         u = t * G - 8 * t * (t - 1) + (g - 16 * t)
         return (u - self.unit_begin) * UNIT_PAIRS + (rows % 8) * 128 + (cols % 128)
 
+    def k_and_int0(self, idx) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """(k int64 [m, 2], int0 bool [m, 2], escape bool [m, 2]) of the cells at flat indices ``idx`` (host arrays);
+        k of an escape cell is -1."""
+        ix = torch.as_tensor(np.asarray(idx, dtype=np.int64), device=self.cells.device)
+        if self.ld32 is not None:
+            v = self.ld32[ix].cpu().numpy()
+            esc = np.isnan(v)
+            k = np.where(esc, -1, np.rint(np.nan_to_num(v).astype(np.float64) * 1e4)).astype(np.int64)
+            return k, np.signbit(v) & (v == 0), esc
+        u = self.k16[ix].cpu().numpy().view(np.uint16).astype(np.int64)
+        int0 = (u & _lib.K16_INT0) != 0
+        esc = u == _lib.K16_BIG
+        return np.where(esc, -1, np.where(int0, 0, u)), int0, esc
+
     def dense(self, measure: str = "r_square", thres: Optional[float] = None,
               rows: Optional[Tuple[int, int]] = None) -> torch.Tensor:
         """ld_two_dim of ld_triangle.py:114,223-230 as float32 [rows][n_snps] on the device.
 
         Cells the reference leaves at the template's int 0 (row <= col, or rounded measure below
         ``thres``) hold -0.0; a computed int 0 (monomorphic variant) is -0.0 too, a float 0.0 is +0.0.
-        Needs the full triangle (unit_begin == 0 and all units present).
+        Escape cells come out as NaN (``dense_values`` resolves them).  Needs the full triangle.
         """
         if self.unit_begin != 0 or self.unit_end != lib.ldx_triangle_units(self.n_snps):
             raise _lib.LdxError("dense() needs an unsharded TriangleResult")
         r0, r1 = rows if rows is not None else (0, self.n_snps)
-        out = torch.empty((r1 - r0, self.n_snps), dtype=torch.float32, device=self.ld32.device)
-        check(lib.ldx_triangle_dense_dev(self.ld32.data_ptr(), self.n_snps, MEASURES[measure],
-                                         0 if thres is None else 1, 0.0 if thres is None else float(thres),
-                                         r0, r1, out.data_ptr(), self.n_snps, _stream_ptr()),
-              "ldx_triangle_dense_dev")
+        out = torch.empty((r1 - r0, self.n_snps), dtype=torch.float32, device=self.cells.device)
+        check(lib.ldx_triangle_dense_ex_dev(self.cells.data_ptr(), _lib.FORMATS[self.fmt], self.n_snps,
+                                            MEASURES[measure], 0 if thres is None else 1,
+                                            0.0 if thres is None else float(thres), r0, r1, out.data_ptr(),
+                                            self.n_snps, _stream_ptr()), "ldx_triangle_dense_ex_dev")
         return out
+
+    def dense_values(self, measure: str = "r_square", thres: Optional[float] = None,
+                     rows: Optional[Tuple[int, int]] = None):
+        """``dense`` on the host plus the exact values of its escape cells: (float32 array [rows][n_snps],
+        {(row, col): Python value}).  The dict holds, for every NaN cell of the array, what the reference's
+        ld_two_dim holds there: round(x, 4) as a float, or the int 0 when it lies below ``thres``
+        (ld_triangle.py:223-230)."""
+        r0, _ = rows if rows is not None else (0, self.n_snps)
+        d = self.dense(measure, thres, rows).cpu().numpy()
+        rr, cc = np.nonzero(np.isnan(d))
+        fixes = {}
+        if rr.size:
+            if self.panel is None:
+                raise _lib.LdxError("escape cells need the panel (TriangleResult.panel) to be resolved")
+            ex = ld_pairs(self.panel, rr + r0, cc)
+            col = 0 if measure == "r_square" else 1
+            for a, b, k in zip((rr + r0).tolist(), cc.tolist(), ex["k"][:, col].tolist()):
+                v = k / 10000.0
+                fixes[(a, b)] = 0 if (thres is not None and v < thres) else v
+        return d, fixes
 
 
 def ld_triangle(panel: PackedPanel, unit_range: Optional[Tuple[int, int]] = None, want_raw: bool = False,
-                want_n11: bool = False, out: Optional[TriangleResult] = None) -> TriangleResult:
+                want_n11: bool = False, out: Optional[TriangleResult] = None, fmt: str = "ld32",
+                path: Optional[str] = None) -> TriangleResult:
     """All row > col pairs of the panel: var_1 = row, var_2 = col (ld_triangle.py:193-194).
 
     ``unit_range`` restricts the work to a contiguous slice of the unit list (multi-GPU sharding);
-    ``out`` re-uses the buffers of a previous result of the same shape (benchmark loops).
+    ``out`` re-uses the buffers of a previous result of the same shape (benchmark loops); ``fmt`` picks the cell
+    format ('ld32': 8 bytes per pair, 'k16': 4 bytes per pair); ``path`` overrides the process-wide kernel choice
+    ('fp4', 'mfma', 'popcount') for this call.
     """
     total = panel.n_units
     u0, u1 = (0, total) if unit_range is None else unit_range
     u0, u1 = max(0, u0), min(total, u1)
     cells = max(0, u1 - u0) * UNIT_PAIRS
     dev = panel.device
+    if fmt not in _lib.FORMATS:
+        raise _lib.LdxError(f"unknown cell format {fmt!r}")
+    if fmt == "k16" and want_raw:
+        raise _lib.LdxError("the unrounded output travels with the ld32 format only")
     if out is None:
-        out = TriangleResult(panel.n_snps, u0, u1, torch.empty((cells, 2), dtype=torch.float32, device=dev),
+        out = TriangleResult(panel.n_snps, u0, u1,
+                             torch.empty((cells, 2), dtype=torch.float32, device=dev) if fmt == "ld32" else None,
                              torch.empty((cells, 2), dtype=torch.float64, device=dev) if want_raw else None,
-                             torch.empty(cells, dtype=torch.int32, device=dev) if want_n11 else None)
-    elif (out.n_snps, out.unit_begin, out.unit_end) != (panel.n_snps, u0, u1):
-        raise _lib.LdxError("ld_triangle: `out` has a different shape")
+                             torch.empty(cells, dtype=torch.int32, device=dev) if want_n11 else None,
+                             torch.empty((cells, 2), dtype=torch.int16, device=dev) if fmt == "k16" else None)
+    elif (out.n_snps, out.unit_begin, out.unit_end, out.fmt) != (panel.n_snps, u0, u1, fmt):
+        raise _lib.LdxError("ld_triangle: `out` has a different shape or format")
+    out.panel = panel
     if cells:
-        check(lib.ldx_triangle_dev(panel.alt.data_ptr(), panel.fa.data_ptr(), panel.fr.data_ptr(),
-                                   panel.q.data_ptr(), panel.n_snps, panel.n_hap, u0, u1, out.ld32.data_ptr(),
-                                   _ptr(out.raw), _ptr(out.n11), _stream_ptr()), "ldx_triangle_dev")
+        pcode = lib.ldx_get_triangle_path() if path is None else PATHS[path]
+        check(lib.ldx_triangle_ex_dev(panel.alt.data_ptr(), panel.fa.data_ptr(), panel.fr.data_ptr(),
+                                      panel.q.data_ptr(), panel.n_snps, panel.n_hap, u0, u1, pcode,
+                                      _lib.FORMATS[fmt], out.cells.data_ptr(), _ptr(out.raw), _ptr(out.n11),
+                                      _stream_ptr()), "ldx_triangle_ex_dev")
     return out
 
 
-# --------------------------------------------------------------------------- n11 block / epilogue
+# --------------------------------------------------------------------------- n11 block / epilogue / explicit pairs
 def pair_counts(panel_i: PackedPanel, panel_j: Optional[PackedPanel] = None) -> torch.Tensor:
     """n11[i][j] = #haplotypes with code 1 at SNP i of panel_i and SNP j of panel_j (calc_ld.py:32)."""
     pj = panel_j or panel_i
@@ -127,10 +189,34 @@ def pair_counts(panel_i: PackedPanel, panel_j: Optional[PackedPanel] = None) -> 
     return out
 
 
-def ld_from_counts(n: int, n11, a1, r1, a2, r2, device: Optional[torch.device] = None):
+def ld_pairs(panel: PackedPanel, rows, cols) -> dict:
+    """calc_ld for an explicit list of pairs (var_1 = rows[p], var_2 = cols[p]) of one panel, exact for any magnitude:
+    host arrays ``k`` (float64 [m, 2]: round(x, 4) * 10^4 of r_square, d_prime), ``raw`` (float64 [m, 2]), ``flags``
+    (uint8, LDX_FLAG_*: which value is the reference's int 0) and ``n11`` (uint32)."""
+    dev = panel.device
+    r = torch.as_tensor(np.ascontiguousarray(np.asarray(rows, dtype=np.int64).astype(np.int32))).to(dev)
+    c = torch.as_tensor(np.ascontiguousarray(np.asarray(cols, dtype=np.int64).astype(np.int32))).to(dev)
+    m = int(r.numel())
+    if int(c.numel()) != m:
+        raise _lib.LdxError("ld_pairs: rows and cols differ in length")
+    k = torch.empty((m, 2), dtype=torch.float64, device=dev)
+    raw = torch.empty((m, 2), dtype=torch.float64, device=dev)
+    flags = torch.empty(m, dtype=torch.uint8, device=dev)
+    n11 = torch.empty(m, dtype=torch.int32, device=dev)
+    if m:
+        check(lib.ldx_ld_pairs_dev(panel.alt.data_ptr(), panel.acnt.data_ptr(), panel.rcnt.data_ptr(), panel.n_snps,
+                                   panel.n_hap, r.data_ptr(), c.data_ptr(), m, k.data_ptr(), raw.data_ptr(),
+                                   flags.data_ptr(), n11.data_ptr(), _stream_ptr()), "ldx_ld_pairs_dev")
+    return {"k": k.cpu().numpy(), "raw": raw.cpu().numpy(), "flags": flags.cpu().numpy(),
+            "n11": n11.cpu().numpy().view(np.uint32)}
+
+
+def ld_from_counts(n: int, n11, a1, r1, a2, r2, device: Optional[torch.device] = None, full: bool = False):
     """The epilogue alone (calc_ld.py:33-97) on arrays of counts.
 
-    Returns (raw float64 [m,2], rounded float32 [m,2], flags uint8 [m]) as device tensors.
+    Returns (raw float64 [m,2], rounded float32 [m,2], flags uint8 [m]) as device tensors; with ``full`` also
+    k (float64 [m,2]: round(x, 4) * 10^4, exact for any magnitude) and the 4-byte cells (int16 [m,2], the bit patterns
+    of ldx_k16).
     """
     dev = device or torch.device("cuda", torch.cuda.current_device())
     def up(x):
@@ -141,9 +227,13 @@ def ld_from_counts(n: int, n11, a1, r1, a2, r2, device: Optional[torch.device] =
     raw = torch.empty((m, 2), dtype=torch.float64, device=dev)
     rnd = torch.empty((m, 2), dtype=torch.float32, device=dev)
     flags = torch.empty(m, dtype=torch.uint8, device=dev)
-    check(lib.ldx_ld_from_counts_dev(int(n), m, t11.data_ptr(), ta1.data_ptr(), tr1.data_ptr(), ta2.data_ptr(),
-                                     tr2.data_ptr(), raw.data_ptr(), rnd.data_ptr(), flags.data_ptr(),
-                                     _stream_ptr()), "ldx_ld_from_counts_dev")
+    k = torch.empty((m, 2), dtype=torch.float64, device=dev) if full else None
+    k16 = torch.empty((m, 2), dtype=torch.int16, device=dev) if full else None
+    check(lib.ldx_ld_from_counts_ex_dev(int(n), m, t11.data_ptr(), ta1.data_ptr(), tr1.data_ptr(), ta2.data_ptr(),
+                                        tr2.data_ptr(), raw.data_ptr(), _ptr(k), rnd.data_ptr(), _ptr(k16),
+                                        flags.data_ptr(), _stream_ptr()), "ldx_ld_from_counts_ex_dev")
+    if full:
+        return raw, rnd, flags, k, k16
     return raw, rnd, flags
 
 
@@ -166,6 +256,23 @@ class AreaHits:
 
     def __len__(self) -> int:
         return int(self.query.numel())
+
+    def python_values(self, panel: PackedPanel):
+        """[(r_square, d_prime)] per hit as the reference's Python values (float round(x, 4), or the int 0).  Hits whose
+        float32 is the escape NaN (a value >= 1024: only with missing codes) are resolved exactly through ld_pairs."""
+        v = self.ld32.cpu().numpy().reshape(-1, 2)
+        esc = np.isnan(v)
+        k = np.rint(np.where(esc, 0, v).astype(np.float64) * 1e4)
+        int0 = np.signbit(v) & (v == 0)
+        out = [[0 if z else kk / 10000.0 for kk, z in zip(kr.tolist(), zr.tolist())] for kr, zr in zip(k, int0)]
+        rows = np.flatnonzero(esc.any(axis=1))
+        if rows.size:
+            ex = ld_pairs(panel, self.query.cpu().numpy()[rows], self.oppos.cpu().numpy()[rows])
+            for r, kk in zip(rows.tolist(), ex["k"]):
+                for c in (0, 1):
+                    if esc[r, c]:
+                        out[r][c] = float(kk[c]) / 10000.0
+        return [tuple(x) for x in out]
 
 
 def ld_area(panel: PackedPanel, positions, queries: Optional[Sequence[int]] = None, flank: int = 100000,

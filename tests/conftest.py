@@ -58,3 +58,23 @@ def tri_pairs(n):
     rows = np.concatenate([np.full(i, i, dtype=np.int64) for i in range(n)]) if n > 1 else np.zeros(0, np.int64)
     cols = np.concatenate([np.arange(i, dtype=np.int64) for i in range(n)]) if n > 1 else np.zeros(0, np.int64)
     return rows, cols
+
+
+def realise(n, n11, a1, r1, a2, r2):
+    """Two code lists (codes 0, 1, 2) with exactly these counts (as tests/golden/make_golden.py builds them)."""
+    o1, o2 = n - a1 - r1, n - a2 - r2
+    assert min(o1, o2, n11, a1 - n11, a2 - n11) >= 0
+    row = {1: a1 - n11, 0: r1, 2: o1}
+    col = {1: a2 - n11, 0: r2, 2: o2}
+    cells = {(1, 1): n11}
+    for (rc, cc) in [(1, 0), (1, 2), (0, 1), (2, 1), (0, 0), (0, 2), (2, 0), (2, 2)]:
+        take = min(row[rc], col[cc])
+        cells[(rc, cc)] = take
+        row[rc] -= take
+        col[cc] -= take
+    assert not any(row.values()) and not any(col.values())
+    g1, g2 = [], []
+    for (rc, cc), k in cells.items():
+        g1 += [rc] * k
+        g2 += [cc] * k
+    return g1, g2

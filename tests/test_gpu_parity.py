@@ -65,6 +65,27 @@ def flags_of(ld32: np.ndarray) -> np.ndarray:
     return (int0_of(ld32[:, 1]).astype(np.uint8) * 1) | (int0_of(ld32[:, 0]).astype(np.uint8) * 2)
 
 
+def check_cells(k_true: np.ndarray, flags_true: np.ndarray, ld32: np.ndarray, k16: np.ndarray, tag=None):
+    """Both cell formats against the exact k [m, 2] (r_square, d_prime) and the int-0 flags: every value the format
+    can hold is exact, every other one is the format's escape -- never a wrong number."""
+    k_true = np.asarray(k_true, dtype=np.float64).reshape(-1, 2)
+    int0 = np.stack([(flags_true & 2) != 0, (flags_true & 1) != 0], axis=1)
+    ld32 = np.asarray(ld32, dtype=np.float32).reshape(-1, 2)
+    big32 = (k_true >= 1.024e7) & ~int0
+    assert np.array_equal(np.isnan(ld32), big32), tag
+    assert np.array_equal(ld32.view(np.uint32)[big32], np.full(int(big32.sum()), 0x7FC00B16, np.uint32)), tag
+    assert np.array_equal(np.signbit(ld32) & ~big32, int0), tag
+    ok = ~big32
+    assert np.array_equal(np.rint(ld32[ok].astype(np.float64) * 1e4), np.where(int0, 0, k_true)[ok]), tag
+    assert np.array_equal(ld32[ok], np.where(int0, -0.0, k_true / 1e4).astype(np.float32)[ok]), tag   # the nearest float32
+    u = np.asarray(k16).reshape(-1, 2).view(np.uint16).astype(np.int64)
+    big16 = (k_true >= 32767) & ~int0
+    assert np.array_equal(u == 0x7FFF, big16), tag
+    assert np.array_equal(u == 0x8000, int0), tag
+    rest = ~big16 & ~int0
+    assert np.array_equal(u[rest], k_true[rest].astype(np.int64)), tag
+
+
 # ------------------------------------------------------------------ packing
 @pytest.mark.parametrize("name", list(PANELS))
 def test_pack_matches_oracle(gpu, name, panel_codes):
@@ -179,8 +200,13 @@ def test_epilogue_small_n_exhaustive(gpu, small_n):
     for n in np.unique(counts[:, 0]):
         m = counts[:, 0] == n
         c = counts[m]
-        raw, rnd, flags = ld_from_counts(int(n), c[:, 1], c[:, 2], c[:, 3], c[:, 4], c[:, 5])
+        raw, rnd, flags, k, k16 = ld_from_counts(int(n), c[:, 1], c[:, 2], c[:, 3], c[:, 4], c[:, 5], full=True)
         rnd = rnd.cpu().numpy()
+        k = k.cpu().numpy()
+        assert np.array_equal(k[:, 0], small_n["k_rsq"][m]) and np.array_equal(k[:, 1], small_n["k_dp"][m])   # exact k
+        check_cells(k, small_n["flags"][m], rnd, k16.cpu().numpy(), int(n))  # both formats; a tier mismatch poisons
+        small = (small_n["k_rsq"][m] < 1e7) & (small_n["k_dp"][m] < 1e7)
+        assert small.all()
         assert np.array_equal(k_of(rnd[:, 0]), small_n["k_rsq"][m])          # 4-decimal r^2, exact
         assert np.array_equal(k_of(rnd[:, 1]), small_n["k_dp"][m])           # 4-decimal D', exact
         assert np.array_equal(flags.cpu().numpy(), small_n["flags"][m])      # int 0 vs float 0.0
@@ -220,16 +246,17 @@ def test_epilogue_random_tuples_at_panel_sizes(gpu, n):
     n11 = np.where(kind == 5, rng.choice([0, 1], m) * hi + (1 - rng.choice([0, 1], m)) * lo, n11)
     n11 = np.clip(n11, np.where(kind == 3, 0, lo), hi)
     arrs = [x.astype(np.uint32) for x in (n11, a1, r1, a2, r2)]
-    raw, rnd, flags = ld_from_counts(n, *arrs)
-    rnd, flags = rnd.cpu().numpy(), flags.cpu().numpy()
+    raw, rnd, flags, k, k16 = ld_from_counts(n, *arrs, full=True)
+    rnd, flags, k = rnd.cpu().numpy(), flags.cpu().numpy(), k.cpu().numpy()
     o_rsq_raw, o_dp_raw, o_rsq, o_dp, o_flags = c_oracle.ld_from_counts_v(n, *arrs, libm_pow=True)
-    assert not np.isnan(rnd).any()                                            # the epilogue variants agree
     assert np.array_equal(flags, o_flags)
-    assert np.array_equal(flags_of(rnd), o_flags)
-    small = (o_rsq < 1000.0) & (o_dp < 1000.0)       # float32(k / 1e4) identifies k while ulp < 1e-4, i.e. below 1024
-    assert small.mean() > 0.99
-    assert np.array_equal(k_of(rnd[small, 0]), np.rint(o_rsq[small] * 1e4).astype(np.int64))
-    assert np.array_equal(k_of(rnd[small, 1]), np.rint(o_dp[small] * 1e4).astype(np.int64))
+    # k itself (a double: exact for any magnitude) against the oracle's round(x, 4); k / 1e4 is that very double
+    assert np.array_equal(k[:, 0] / 1e4, o_rsq) and np.array_equal(k[:, 1] / 1e4, o_dp)
+    # both cell formats: exact where they can hold the value, their escape where they cannot; a disagreement
+    # between the epilogue tiers would poison the cell (plain NaN / 0xFFFF) and fail here
+    check_cells(k, o_flags, rnd, k16.cpu().numpy(), n)
+    small = (o_rsq < 1000.0) & (o_dp < 1000.0)
+    assert small.mean() > 0.99 and (~small).any()
     raw = raw.cpu().numpy()
     assert np.array_equal(raw[:, 1], o_dp_raw)                                # unrounded D': bit-identical
     assert np.max(np.abs(raw[:, 0] - o_rsq_raw) / np.maximum(1.0, np.abs(o_rsq_raw))) <= 1e-6
@@ -240,16 +267,15 @@ def test_epilogue_kat(gpu, kat):
 
     for item in kat["tuples"]:
         n, n11, a1, r1, a2, r2 = item["counts"]
-        raw, rnd, flags = ld_from_counts(n, [n11], [a1], [r1], [a2], [r2])
+        raw, rnd, flags, k, k16 = ld_from_counts(n, [n11], [a1], [r1], [a2], [r2], full=True)
         e = item["expect"]
         f = int(flags[0])
-        # the float32 cell identifies k = value * 10^4 while its ulp is below 1e-4 (values below 1024); the D' >> 1
-        # tuples (a + r < n with a vanishing bound) are checked through the unrounded fp64 output instead
-        pick = lambda col, w: round(float(rnd[0, col]), 4) if w < 1000 else round(float(raw[0, col]), 4)  # noqa: E731
-        got_r = 0 if f & 2 else pick(0, e["r_square"])
-        got_d = 0 if f & 1 else pick(1, e["d_prime"])
+        # k / 10^4 in double IS the reference's round(x, 4), whatever the magnitude (the D' >> 1 tuples included)
+        got_r = 0 if f & 2 else float(k[0, 0]) / 1e4
+        got_d = 0 if f & 1 else float(k[0, 1]) / 1e4
         assert got_r == e["r_square"] and type(got_r) is type(e["r_square"]), item
         assert got_d == e["d_prime"] and type(got_d) is type(e["d_prime"]), item
+        check_cells(k.cpu().numpy(), flags.cpu().numpy(), rnd.cpu().numpy(), k16.cpu().numpy(), item)
 
 
 # ------------------------------------------------------------------ ld_triangle
@@ -294,6 +320,96 @@ def test_triangle_dense_and_thresholds(gpu, path, drivers, panel_codes):
                     assert g == 0 and np.signbit(g), (key, i, j)          # int 0 <-> -0.0f
                 else:
                     assert not (g == 0 and np.signbit(g)) and round(float(g), 4) == w, (key, i, j, g, w)
+
+
+def _panel_with_huge_values(n_extra=70, h=5008):
+    """A panel whose pair (1, 0) is the known-answer tuple (5008, 40, 40, 4000, 60, 1) of the reference:
+    r_square 4080.4507, d_prime 4948.0 (a + r < n with a vanishing bound), among ordinary SNPs and a second
+    missing-code row that gives values between 3.2767 and 1024."""
+    from conftest import realise
+    from ld_tools_amd import synth
+
+    g1, g2 = realise(5008, 40, 40, 4000, 60, 1)
+    codes = synth.synth_codes_host(n_extra + 3, h, seed=33, miss=0.0)
+    codes[0] = np.array(g2, dtype=np.int8)         # var_2 of the tuple (the column)
+    codes[1] = np.array(g1, dtype=np.int8)         # var_1 (the row)
+    g3, g4 = realise(5008, 30, 60, 4000, 40, 400)  # a milder one on rows (3, 2)
+    codes[2] = np.array(g4, dtype=np.int8)
+    codes[3] = np.array(g3, dtype=np.int8)
+    return codes
+
+
+def test_triangle_k16_cells_equal_ld32_cells(gpu, path):
+    """The 4-byte cell format carries the same (k, int-0) as the 8-byte one for every cell either can hold, on all
+    three kernels, with missing codes, monomorphic rows and values beyond both formats in the panel."""
+    import torch
+    from ld_tools_amd import PackedPanel, ld_triangle, ops
+    from oracle import c_oracle
+
+    codes = _panel_with_huge_values()
+    codes[10] = 0
+    codes[11, ::5] = 2
+    p = PackedPanel.from_codes(codes)
+    a = ld_triangle(p, want_n11=True)
+    b = ld_triangle(p, want_n11=True, fmt="k16")
+    assert b.k16.dtype == torch.int16 and b.ld32 is None and b.fmt == "k16"
+    assert torch.equal(a.n11, b.n11)
+    n = p.n_snps
+    rows, cols = np.tril_indices(n, -1)
+    idx = a.cell_index(rows, cols)
+    o = c_oracle.Panel(codes).triangle(libm_pow=True, want=("rsq_rnd", "dp_rnd", "flags"))
+    k_true = np.stack([np.rint(o["rsq_rnd"][rows, cols] * 1e4), np.rint(o["dp_rnd"][rows, cols] * 1e4)], axis=1)
+    check_cells(k_true, o["flags"][rows, cols], a.ld32.cpu().numpy()[idx], b.k16.cpu().numpy()[idx], path)
+    assert (k_true >= 1.024e7).any() and ((k_true >= 32767) & (k_true < 1.024e7)).any()
+    # cells outside the triangle are zero in both formats
+    mask = np.ones(len(b.k16), dtype=bool)
+    mask[idx] = False
+    assert not b.k16.cpu().numpy()[mask].any() and not a.ld32.cpu().numpy()[mask].any()
+    # k_and_int0 decodes both the same way
+    ka, za, ea = a.k_and_int0(idx)
+    kb, zb, eb = b.k_and_int0(idx)
+    both = ~ea & ~eb
+    assert np.array_equal(ka[both], kb[both]) and np.array_equal(za, zb) and (ea <= eb).all()
+    # the dense matrices agree wherever neither is an escape; k16's escapes are a superset
+    for measure, thres in (("r_square", None), ("d_prime", 0.3), ("r_square", 0.05)):
+        da, db = a.dense(measure, thres).cpu().numpy(), b.dense(measure, thres).cpu().numpy()
+        ok = ~np.isnan(da) & ~np.isnan(db)
+        assert np.array_equal(da[ok].view(np.uint32), db[ok].view(np.uint32)), (measure, thres)
+        assert (np.isnan(da) <= np.isnan(db)).all() and np.isnan(da).any()
+        # ... and the escapes resolve to the reference's values in both
+        va, fa_ = a.dense_values(measure, thres)
+        vb, fb_ = b.dense_values(measure, thres)
+        col = o["rsq_rnd"] if measure == "r_square" else o["dp_rnd"]
+        for fixes in (fa_, fb_):
+            assert fixes
+            for (i, j), val in fixes.items():
+                want = float(col[i, j]) if (thres is None or col[i, j] >= thres) else 0
+                assert val == want and type(val) is type(want), (measure, thres, i, j, val, want)
+        assert {k: v for k, v in fb_.items() if k in fa_} == fa_
+    assert a.dense_values("r_square")[1][(1, 0)] == 4080.4507 and a.dense_values("d_prime")[1][(1, 0)] == 4948.0
+
+
+def test_ld_pairs_exact_for_any_magnitude(gpu):
+    from ld_tools_amd import PackedPanel, ops
+    from oracle import c_oracle
+
+    codes = _panel_with_huge_values()
+    p = PackedPanel.from_codes(codes)
+    rng = np.random.RandomState(5)
+    rows = np.concatenate([[1, 3, 0, 2], rng.randint(0, p.n_snps, 500)])
+    cols = np.concatenate([[0, 2, 1, 3], rng.randint(0, p.n_snps, 500)])      # any order, repeats, row == col too
+    got = ops.ld_pairs(p, rows, cols)
+    oc = c_oracle.Panel(codes)
+    n11 = np.array([oc.pair_counts(int(r), int(r) + 1, int(c), int(c) + 1)[0, 0] for r, c in zip(rows, cols)], np.uint32)
+    assert np.array_equal(got["n11"], n11)
+    rsq_raw, dp_raw, rsq, dp, flags = c_oracle.ld_from_counts_v(p.n_hap, n11, oc.acnt[rows], oc.rcnt[rows], oc.acnt[cols],
+                                                                oc.rcnt[cols], libm_pow=True)
+    assert np.array_equal(got["k"][:, 0] / 1e4, rsq) and np.array_equal(got["k"][:, 1] / 1e4, dp)
+    assert np.array_equal(got["flags"], flags)
+    assert np.array_equal(got["raw"][:, 1], dp_raw)
+    assert got["k"][0, 0] == 40804507 and got["k"][0, 1] == 49480000
+    with pytest.raises(Exception):
+        ops.ld_pairs(p, [0, 1], [0])
 
 
 def test_triangle_sharded_units_equal_full(gpu, path):
@@ -596,6 +712,28 @@ def test_area_banded_against_oracle(gpu, area_path):
         assert hits.n_pairs == int((hi - lo).sum() - (flank > 0) * len(qs))
 
 
+def test_area_hits_beyond_the_float_cell(gpu, area_path):
+    """A (query, opposing) pair whose r^2 / D' exceed 1024 (missing codes, vanishing bound) is a hit for every threshold
+    and comes back with its exact value -- 4080.4507 / 4948.0 for the reference's own known-answer tuple."""
+    from ld_tools_amd import PackedPanel, ld_area
+    from oracle import c_oracle
+
+    codes = _panel_with_huge_values()
+    p = PackedPanel.from_codes(codes)
+    pos = 100 + 10 * np.arange(p.n_snps)
+    for measure, thres in (("r_square", 0.8), ("d_prime", 0.99), ("r_square", 0.0)):
+        hits = ld_area(p, pos, None, 10 ** 6, measure, thres)
+        hq, ho, hr, hd, hf = c_oracle.Panel(codes).area(pos, np.arange(p.n_snps), 10 ** 6, 0 if measure == "r_square" else 1,
+                                                         thres, libm_pow=True)
+        assert np.array_equal(hits.query.cpu().numpy(), hq) and np.array_equal(hits.oppos.cpu().numpy(), ho)
+        vals = hits.python_values(p)
+        want = [(0 if f & 2 else r, 0 if f & 1 else d) for r, d, f in zip(hr.tolist(), hd.tolist(), hf.tolist())]
+        assert [tuple(map(str, v)) for v in vals] == [tuple(map(str, w)) for w in want]
+        k = [i for i, (a, b) in enumerate(zip(hq, ho)) if (a, b) == (1, 0)]
+        assert len(k) == 1 and vals[k[0]] == (4080.4507, 4948.0)
+        assert np.isnan(hits.ld32.cpu().numpy()[k[0]]).all()
+
+
 def test_area_rejects_unsorted_positions(gpu):
     from ld_tools_amd import LdxError, PackedPanel, ld_area, synth
 
@@ -682,15 +820,17 @@ def test_calc_ld_dropin(gpu, kat):
         for k, w in item["expect"].items():
             assert got[k] == w and type(got[k]) is type(w), (item, k, got[k])
         assert str(got) == str(item["expect"])
-    for item in kat["tuples"][:12]:
+    from conftest import realise
+    for item in kat["tuples"]:                       # all of them, the D' >> 1 ones (values >= 1024) included
         n, n11, a1, r1, a2, r2 = item["counts"]
-        g1 = [1] * n11 + [1] * (a1 - n11) + [0] * (n - a1)
-        g2 = [1] * n11 + [0] * (a1 - n11) + [1] * (a2 - n11) + [0] * (n - a1 - a2 + n11)
-        if r1 != n - a1 or r2 != n - a2 or len(g2) != n:
-            continue
+        g1, g2 = realise(n, n11, a1, r1, a2, r2)
         got, counts, raw, flags = calc_ld_full(g1, g2)
         assert counts == (n, n11, a1, r1, a2, r2)
-        assert str(got) == str(item["expect"])
+        assert str(got) == str(item["expect"]), item
+        for key, w in item["expect"].items():
+            assert got[key] == w and type(got[key]) is type(w), (item, key)
+    long = [1, 0] * 20000                            # no LDX_MAX_HAPS limit on the pair-by-pair path
+    assert calc_ld(long, long[1:] + [0])["var_1_alt_freq"] == 0.5
     with pytest.raises(ZeroDivisionError):
         calc_ld([], [1])
     assert str(calc_ld(np.array([1, 0, 1, 0]), np.array([1, 1, 0, 0]))) == str(calc_ld([1, 0, 1, 0], [1, 1, 0, 0]))
