@@ -56,6 +56,7 @@ extern "C" {
 /* per-pair flag bits: which results are the reference's *int* 0 rather than a float */
 #define LDX_FLAG_DPRIME_INT0 1u    /* calc_ld.py:68-69,75-76 (ZeroDivisionError branch) */
 #define LDX_FLAG_RSQ_INT0 2u       /* calc_ld.py:89-90 (unrounded d_prime == 0) */
+#define LDX_FLAG_F32_SURE 0x80u     /* ldx_ld_from_counts_ex_dev only: the fp32 epilogue tier would keep this pair */
 
 /* measures (ld_triangle -l / ld_area -l: ld_triangle_cli_en.py:52, ld_area_cli_en.py:50) */
 #define LDX_MEASURE_RSQ 0
@@ -250,6 +251,10 @@ int ldx_probe_mfma_dev(uint32_t *sink, uint32_t blocks, uint32_t threads, uint32
 /* Tests / tuning: force the number of passes a matrix-kernel launch hands out as two half-height tickets
  * (n_short >= 0), or restore the launch heuristic (n_short < 0).  Results do not depend on it. */
 int ldx_debug_force_short_passes(int n_short);
+/* Tuning builds (-DLDX_TUNING) count events of the fp32 epilogue tier: out[0] = units it handled, [1] = lane-steps parked
+ * for the fp64 tier, [2] = units redone because the queue overflowed, [3] = mirror evaluations behind the fp64 tier.
+ * Product builds leave the counters at zero.  Synchronises the device. */
+int ldx_debug_counters(uint64_t out[8], int reset);
 
 #ifdef __cplusplus
 }

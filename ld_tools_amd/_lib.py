@@ -98,6 +98,7 @@ SIGNATURES = {
     "ldx_ld_from_counts_ex_dev": (_int, [_u32, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ldx_ld_pairs_dev": (_int, [_vp, _vp, _vp, _u32, _u32, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     "ldx_debug_force_short_passes": (_int, [_int]),
+    "ldx_debug_counters": (_int, [_vp, _int]),
     "ldx_set_triangle_path": (_int, [_int]),
     "ldx_get_triangle_path": (_int, []),
     "ldx_triangle_dense_dev": (_int, [_vp, _u32, _int, _int, _dbl, _u32, _u32, _vp, _sz, _vp]),

@@ -22,7 +22,7 @@ HEADERS = [CSRC / "ldx_common.h", CSRC / "ldx_tile.h", PKG.parent / "include" / 
 # -ffp-contract=off: the epilogue must round every product and sum separately (calc_ld.py:50);
 # hipcc's default for device code is fp-contract=fast.
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-ffp-contract=off",
-         "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+         "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
 
 
 def hipcc() -> str:

@@ -296,9 +296,13 @@ __device__ __forceinline__ FastCol fast_col(double fa, double fr, double n)
 // (register pressure beside 128 live accumulators), every fp64 instruction then waits for its predecessor's
 // result, and a lone epilogue wave ran at ~10 cycles per instruction instead of the 4-5 it can issue.  The
 // sched_barriers pin "all W pairs, one stage" as the instruction order.
+#ifdef LDX_NOSTAGE   // tuning: leave the order to the compiler
+#define LDX_STAGE(body) _Pragma("unroll") for (int t_ = 0; t_ < W; ++t_) { body; }
+#else
 #define LDX_STAGE(body)                                  \
     _Pragma("unroll") for (int t_ = 0; t_ < W; ++t_) { body; } \
     __builtin_amdgcn_sched_barrier(0);
+#endif
 
 // kClean: the caller has established that no operand is degenerate (every count > 0) and that no SNP has missing
 // codes (a + r == n, hence D' <= 1 and r^2 <= 1 up to rounding): the inf test, the int-0 selects and the y < 1e7
@@ -339,6 +343,97 @@ __device__ __forceinline__ void ld_multi_fast2(const T (&cnt_scaled)[W], const F
                          out[t_].r_square = deg[t_] ? (uint16_t)LDX_K16_INT0 : (uint16_t)ur;
                          out[t_].d_prime = deg[t_] ? (uint16_t)LDX_K16_INT0 : (uint16_t)ud;
                          slow[t_] = !((ok[t_] & fits) | deg[t_]); })
+    }
+}
+
+// ---- fp32 first tier (the FP4 matrix kernel's epilogue for units of ordinary SNPs) ------------------------------------
+// The same two quantities, y_r = 10^4 r^2 and y_d = 10^4 D', in float32 from the exact integer Dn -- 25 single-rate
+// VALU instructions per pair instead of ~33 double-rate ones, short enough dependent chains to interleave four pairs
+// -- with a margin test that is wide enough for float32: a lane whose 8 pairs of a step are not ALL provably rounded
+// like the reference hands that step to the fp64 tier above (ld_multi_fast2), through a per-wave queue in LDS, so
+// the common path never branches per pair.  Valid only for ordinary SNPs on both sides (polymorphic, a + r == n:
+// then r^2 <= 1, D' <= 1, B >= 1 and a r >= n - 1, which the error bounds below use).
+//
+// Error budget (u = 2^-24; every table entry is a double-precision value rounded once to float32):
+//   Dn = n c - a1 a2 is computed exactly while |Dn| < 2^24 (p = fl(a1 a2), e = a1 a2 - p exactly by fma,
+//        v = fl(n c - p) is exact there, v - e too); beyond it two roundings: (1 + 2u);
+//   y_r = ((Dn s1) s2)^2, s = 10 / sqrt(a r): rel. error <= 13u;   y_d = |Dn| max(ra1s x, rr1s y): rel. error <= 6u;
+//   the reference's own deviation from the exact rational value, in y units: <= 6e-12 n^2 / B <= 6e-12 n^2 for D'
+//   and <= 1.2e-11 n^2 |Dn| / (a1 r1 a2 r2) <= 1.2e-11 n^2 / (n - 1) for r^2 (the fp64 tier's bounds with B >= 1 and
+//   |Dn| <= sqrt(a1 r1 a2 r2), a r >= n - 1).
+// A pair is sure when  |y - rint(y)| + eta y < 1/2 - c0  for both quantities and Dn != 0 (y_d > 0): then the float32
+// value, the exact value and the reference's double all round to the same integer k.  rint(y) is taken by adding
+// 2^23 (the sum's low mantissa bits ARE k, which is what the 4-byte cell stores).
+struct F32Row {   // per var_1 (row): a, 1e4 / a, 1e4 / r, 10 / sqrt(a r)
+    float a, ra_s, rr_s, s;
+};
+struct F32Col {   // per var_2 (column): a, 1 / a, 1 / r, 10 / sqrt(a r)
+    float a, ra, rr, s;
+};
+struct F32Const {
+    float n;       // haplotypes
+    float tol;     // 1/2 - c0: the margin threshold
+};
+constexpr float kEtaR = 14.0f * 5.9604645e-8f, kEtaD = 7.0f * 5.9604645e-8f;
+constexpr float kMagic = 8388608.0f;   // 2^23
+
+__host__ __device__ inline F32Const f32_const(double n)
+{
+    F32Const c;
+    c.n = (float)n;
+    const double c0 = 6e-12 * n * n + 1.2e-11 * n * n / (n > 2.0 ? n - 1.0 : 1.0) + 2e-6;
+    c.tol = (float)(0.5 - c0);   // rounds to nearest: the 2e-6 covers that and the last-place effects of the test itself
+    return c;
+}
+
+// from the fp64 tier's per-SNP operands (a, 1/a, 1/r as doubles: errors ~1e-16, far below float32's u)
+__device__ __forceinline__ F32Row f32_row(double a, double ra, double rr)
+{
+    return F32Row{(float)a, (float)(1e4 * ra), (float)(1e4 * rr), (float)(10.0 * __builtin_sqrt(ra * rr))};
+}
+
+__device__ __forceinline__ F32Col f32_col(double a, double ra, double rr)
+{
+    return F32Col{(float)a, (float)ra, (float)rr, (float)(10.0 * __builtin_sqrt(ra * rr))};
+}
+
+// float32 nearest to k / 10^4 for an integer-valued float k < 2^15: quotient by the reciprocal plus one exact
+// residual correction (checked exhaustively for 0 <= k < 32768 in tests/test_abi_and_host.py against exact rationals)
+__device__ __forceinline__ float f32_k_to_value(float k)
+{
+    const float c4 = 1e-4f;
+    const float q = k * c4;
+    const float r = __builtin_fmaf(-q, 1e4f, k);
+    return __builtin_fmaf(r, c4, q);
+}
+
+// W pairs, stage by stage.  cnt: n11 as floats; out: the encoded cells (valid where the lane turns out sure);
+// wmax / ymin accumulate the margin quantity and the smallest y_d over the pairs of a step (the caller tests
+// wmax < tol and ymin > 0 once per step).
+template <int W, typename Cell>
+__device__ __forceinline__ void ld_multi_f32(const float (&cnt)[W], const F32Const &k, const F32Row (&r)[W],
+                                             const F32Col (&c)[W], Cell (&out)[W], float &wmax, float &ymin)
+{
+    float p[W], e[W], dn[W], t[W], yr[W], x[W], y[W], yd[W], ar[W], ad[W], kr[W], kd[W], fr_[W], fd[W];
+    __builtin_amdgcn_sched_barrier(0);
+    LDX_STAGE(p[t_] = r[t_].a * c[t_].a)
+    LDX_STAGE(e[t_] = __builtin_fmaf(r[t_].a, c[t_].a, -p[t_]); dn[t_] = __builtin_fmaf(cnt[t_], k.n, -p[t_]))
+    LDX_STAGE(dn[t_] = dn[t_] - e[t_])                                              // Dn, exact below 2^24
+    LDX_STAGE(t[t_] = dn[t_] * r[t_].s; const bool neg = dn[t_] < 0.0f;
+              x[t_] = neg ? c[t_].ra : c[t_].rr; y[t_] = neg ? c[t_].rr : c[t_].ra)
+    LDX_STAGE(t[t_] = t[t_] * c[t_].s; x[t_] = r[t_].ra_s * x[t_]; y[t_] = r[t_].rr_s * y[t_])
+    LDX_STAGE(yr[t_] = t[t_] * t[t_]; x[t_] = __builtin_fmaxf(x[t_], y[t_]))       // 1e4 r^2;  1e4 / B
+    LDX_STAGE(yd[t_] = __builtin_fabsf(dn[t_]) * x[t_]; ar[t_] = yr[t_] + kMagic)   // 1e4 D'
+    LDX_STAGE(ad[t_] = yd[t_] + kMagic; kr[t_] = ar[t_] - kMagic)
+    LDX_STAGE(kd[t_] = ad[t_] - kMagic; fr_[t_] = yr[t_] - kr[t_])
+    LDX_STAGE(fd[t_] = yd[t_] - kd[t_]; fr_[t_] = __builtin_fmaf(yr[t_], kEtaR, __builtin_fabsf(fr_[t_])))
+    LDX_STAGE(fd[t_] = __builtin_fmaf(yd[t_], kEtaD, __builtin_fabsf(fd[t_])))
+    LDX_STAGE(wmax = __builtin_fmaxf(wmax, __builtin_fmaxf(fr_[t_], fd[t_])); ymin = __builtin_fminf(ymin, yd[t_]))
+    if constexpr (std::is_same<Cell, ldx_k16>::value) {   // the low mantissa bits of 2^23 + k are k: one byte permute per cell
+        LDX_STAGE(out[t_] = __builtin_bit_cast(ldx_k16, __builtin_amdgcn_perm(__float_as_uint(ad[t_]), __float_as_uint(ar[t_]),
+                                                                             0x05040100u)))
+    } else {
+        LDX_STAGE(out[t_].r_square = f32_k_to_value(kr[t_]); out[t_].d_prime = f32_k_to_value(kd[t_]))
     }
 }
 #undef LDX_STAGE

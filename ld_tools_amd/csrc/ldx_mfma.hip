@@ -45,6 +45,7 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
@@ -175,7 +176,21 @@ __host__ __device__ inline uint32_t mfma_pass_base(uint32_t t, uint32_t n_slabs)
 // ticket counters of the dynamic pass scheduler: {next ticket, workgroups finished}; one pair per stream (host side:
 // launch_mfma), zeroed before every launch and re-armed by the last workgroup out
 constexpr uint32_t kSchedSlots = 256;
-__device__ uint32_t g_sched[kSchedSlots][2];
+// ... followed by one K-loop token per physical CU (indexed by XCC / SE / SH / CU id).  The two workgroups of a CU share
+// each SIMD's matrix pipe, and a workgroup's four waves are tied together by its per-K-block barrier, so whenever the two
+// are in their K loops at the same time BOTH run at half speed on all four SIMDs -- and left alone that is most of the
+// time (a wave's partner is in its K loop about half the time, independently per SIMD).  The token lets one workgroup
+// per CU into its K loop at a time; the other is in its epilogue (VALU) or waits.  While the epilogue is not shorter
+// than the K loop nobody waits and each K loop has the matrix pipe to itself.
+constexpr uint32_t kCuSlots = 2048;
+constexpr uint32_t kSchedWords = 2u + kCuSlots;
+__device__ uint32_t g_sched[kSchedSlots][kSchedWords];
+__device__ unsigned long long g_dbg[8];   // tuning builds (-DLDX_TUNING): event counters, see ldx_debug_counters
+#ifdef LDX_TUNING
+#define LDX_COUNT(slot, v) do { if (lane == 0) atomicAdd(&g_dbg[slot], (unsigned long long)(v)); } while (0)
+#else
+#define LDX_COUNT(slot, v)
+#endif
 static std::atomic<int> g_forced_short{-1};   // >= 0: number of halved passes per launch (ldx_debug_force_short_passes)
 
 
@@ -192,8 +207,17 @@ struct AreaArgs {
     uint64_t hit_cap;
     double flank, k_thres;
     int measure;
+    F32Const f32;                  // the fp32 epilogue tier's constants (triangle launches use only this member)
 };
 constexpr uint32_t kHitBatch = 256;   // hit slots a wave reserves per atomic (as in ldx_area.hip)
+constexpr uint32_t kQueueCap = 128;   // fp32 tier: lane-steps a wave can park for the fp64 tier (drained 64 at a time)
+// dynamic LDS of the kernel: the two j-tile image buffers, the fp64 operand tables, tickets, and for the FP4 triangle
+// kernel the fp32 tables and the four queues
+constexpr size_t mfma_lds_bytes(uint32_t stat_rows, bool f32_tier)
+{
+    return 2u * kBBuf + (kSlab + kMfmaWaves * stat_rows) * kStat * sizeof(double) + 32u +
+           (f32_tier ? (kSlab + kMfmaWaves * kRows64) * 16u + kMfmaWaves * kQueueCap * 36u : 0u);
+}
 
 // tuning build -DLDX_MM1: every ticket half-height (32-row accumulator tiles only), three workgroups per CU
 #ifdef LDX_MM1
@@ -280,7 +304,21 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
     // slowest pair set the kernel time (max wave lifetime 826k cycles against a median of 533k at 10k SNPs).
     uint32_t *tickets = reinterpret_cast<uint32_t *>(cstat + kSlab * kStat + kMfmaWaves * ((kArea ? kRows64 : kStatRows) * kStat));   // [2]
     uint32_t *cols_odd = tickets + 2;   // [2]: per wave of the column stagers, != 0 if one of its columns is not "ordinary"
+    // fp32 tier (ldx_common.h, ld_multi_f32): its per-SNP tables and each wave's queue of lane-steps for the fp64 tier
+    constexpr bool kF32Tier = kFp4 && !kRaw && !kN11 && !kArea;
+    float *ctab32 = reinterpret_cast<float *>(tickets + 8);                 // [128][4]: F32Col
+    float *rtab32 = ctab32 + kSlab * 4u + wave * (kRows64 * 4u);            // [64][4]: F32Row, private to the wave
+    uint32_t *qid = reinterpret_cast<uint32_t *>(ctab32 + kSlab * 4u + kMfmaWaves * kRows64 * 4u) + wave * kQueueCap;   // [kQueueCap]
+    float *qcnt = reinterpret_cast<float *>(reinterpret_cast<uint32_t *>(ctab32 + kSlab * 4u + kMfmaWaves * kRows64 * 4u) +
+                                            kMfmaWaves * kQueueCap) + wave * (kQueueCap * 8u);   // [kQueueCap][8] counts
+    const F32Const fc32 = aa.f32;   // computed on the host (f32_const): kernel arguments live in scalar registers
     auto draw = [&]() { return atomicAdd(&sched[0], 1u); };
+    // this CU's K-loop token (triangle launches; the band kernel's epilogue is too short for an alternation to pay)
+    uint32_t *ktok = nullptr;
+    if (!kArea && !(ablate_arg & 4096)) {
+        const uint32_t hw = __builtin_amdgcn_s_getreg(63492), xcc = __builtin_amdgcn_s_getreg(63508);   // HW_ID, XCC_ID
+        ktok = sched + 2u + ((((xcc & 7u) * 8u + ((hw >> 13) & 7u)) * 2u + ((hw >> 12) & 1u)) * 16u + ((hw >> 8) & 15u));
+    }
     uint32_t parity = 0;
     if (tid == 0) tickets[0] = draw();
 
@@ -475,6 +513,10 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                     dst[0] = d2{c.a, c.ra};
                     dst[1] = d2{c.rr, c.rq};
                     if (kArea) dst[2] = j < n_snps ? d2{(double)aa.pos[j], (double)aa.is_query[j]} : d2{0.0, 0.0};
+                    if constexpr (kF32Tier) {
+                        const F32Col c32 = f32_col(c.a, c.ra, c.rr);
+                        *reinterpret_cast<v4f *>(ctab32 + tid * 4u) = v4f{c32.a, c32.ra, c32.rr, c32.s};
+                    }
                 }
                 const uint32_t i = row0 + (MM == 1 ? l32 : lane);   // a half-height unit has 32 rows: stay inside the padded vectors
                 const FastRow r = fast_row(fa[i], fr[i], n);
@@ -485,8 +527,14 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                     dst[0] = d2{r.a_s, r.ra};
                     dst[1] = d2{r.rr, r.rq_s};
                 }
+                if constexpr (kF32Tier && MM == 2) {
+                    const F32Row r32 = f32_row(r.a_s * 1e-4, r.ra, r.rr);   // 1e4 a / 1e4: exact (a < 2^32)
+                    *reinterpret_cast<v4f *>(rtab32 + lane * 4u) = v4f{r32.a, r32.ra_s, r32.rr_s, r32.s};
+                }
                 if (kArea) dst[2] = i < n_snps ? d2{(double)aa.pos[i], (double)aa.is_query[i]} : d2{0.0, 0.0};
             }
+            if (ktok && tid == 0)   // one workgroup per CU in its K loop at a time (see g_sched)
+                while (atomicCAS(ktok, 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(4);
             __syncthreads();
             LDX_STAMP(1);
             if (ablate & 32) __builtin_amdgcn_s_setprio(2);   // tuning: the K-loop wave outranks the epilogue wave instead
@@ -580,7 +628,10 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
             // the next pass's ticket: drawn here (after the K loop's hand-counted loads), stored to LDS after the
             // epilogue, so the atomic's latency hides behind it
             uint32_t next_ticket = 0;
-            if (tid == 0) next_ticket = draw();
+            if (tid == 0) {
+                if (ktok) atomicExch(ktok, 0u);   // the other workgroup of the CU may start its K loop
+                next_ticket = draw();
+            }
             // The epilogue wave outranks the SIMD's other wave (in its K loop, matrix-pipe-bound with issue slots
             // to spare) in instruction arbitration: +2 % at 40k SNPs.
             if (ablate & 32) __builtin_amdgcn_s_setprio(0);
@@ -736,6 +787,156 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                     }
             }
             };
+            // ---- fp32 first tier (FP4 triangle kernel, units of ordinary SNPs wholly inside the triangle and the range) ----
+            // Per step each lane runs its 8 pairs through ld_multi_f32 and tests ONCE whether all of them are provably
+            // rounded like the reference; if so it stores its 8 cells, if not it parks the step (id + 8 counts) in the
+            // wave's LDS queue.  The queue is drained AFTER the sixteen steps -- the accumulators are dead by then, so the
+            // fp64 tier (ld_multi_fast2, and the op-for-op mirror behind it) has the registers it wants -- 64 entries at
+            // a time, one parked step per lane: the rare path runs at full lane occupancy.  A unit that parks more steps
+            // than the queue holds is redone as a whole by the fp64 epilogue (returns false).
+            auto epilogue_f32 = [&]() -> bool {
+              if constexpr (kF32Tier && MM == 2) {
+                if (ablate & 1) return true;   // tuning: no epilogue at all
+                // this unit's cells: a wave-uniform base (scalar registers) + a per-lane constant + a per-step scalar offset
+                const uint64_t ub = vv * 8u - u_begin;
+                Cell *const ubase = out + (((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(ub >> 32)) << 32) |
+                                           __builtin_amdgcn_readfirstlane((uint32_t)ub)) * LDX_UNIT_PAIRS;
+                // the lane's half / column, recomputed HERE from an opaque copy of the lane id: values derived from it at the
+                // top of the kernel would be hoisted out of the pass loop, spilled around the K loop (256 registers) and
+                // reloaded from scratch inside the step loop -- behind a vmcnt(0) that also waits for the step's stores
+                uint32_t ln = lane;
+                asm volatile("" : "+v"(ln));
+                const uint32_t l32e = ln & 31u, halfe = ln >> 5;
+                const uint32_t lane_off = halfe * 4u * kSlab + l32e;   // rows e and e + 4 of a group of 8 belong to the two lane halves
+                const float *const rt = rtab32 + halfe * 16u, *const ct = ctab32 + l32e * 4u;
+                uint32_t qn = 0;   // parked steps (wave-uniform)
+#pragma unroll 1
+                for (int e = 0; e < 16; ++e) {
+                    F32Row rows[2];
+                    F32Col cols[4];
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {   // two addresses per wave: broadcast
+                        const v4f v = *reinterpret_cast<const v4f *>(rt + (32u * m + (e & 3) + 8u * (e >> 2)) * 4u);
+                        rows[m] = F32Row{v.x, v.y, v.z, v.w};
+                    }
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) {   // the column operands come from LDS every step: 16 registers not held
+                        const v4f v = *reinterpret_cast<const v4f *>(ct + 32u * tt * 4u);
+                        cols[tt] = F32Col{v.x, v.y, v.z, v.w};
+                    }
+                    Cell cell[8];
+                    float wmax = 0.0f, ymin = 1.0f;
+#ifdef LDX_F32_W8   // tuning: all eight chains of a step interleaved
+                    {
+                        float c8[8];
+                        F32Row r8[8];
+                        F32Col k8[8];
+#pragma unroll
+                        for (int g = 0; g < 2; ++g)
+#pragma unroll
+                            for (int tt = 0; tt < 4; ++tt) {
+                                c8[g * 4 + tt] = acc[g][tt][e];
+                                r8[g * 4 + tt] = rows[g];
+                                k8[g * 4 + tt] = cols[tt];
+                            }
+                        ld_multi_f32<8, Cell>(c8, fc32, r8, k8, cell, wmax, ymin);
+                    }
+#else
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {   // four interleaved chains at a time: (m, tt) = (g, 0..3)
+                        float c4[4];
+                        F32Row r4[4];
+                        Cell o4[4];
+#pragma unroll
+                        for (int tt = 0; tt < 4; ++tt) {
+                            c4[tt] = acc[g][tt][e];
+                            r4[tt] = rows[g];
+                        }
+                        ld_multi_f32<4, Cell>(c4, fc32, r4, cols, o4, wmax, ymin);
+#pragma unroll
+                        for (int tt = 0; tt < 4; ++tt) cell[g * 4 + tt] = o4[tt];
+                    }
+#endif
+                    const bool sure = ((wmax < fc32.tol) & (ymin > 0.0f)) | ((ablate & 1024) != 0);   // tuning: 1024 = never park
+                    if (sure && !(ablate & 4)) {
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) {
+                            Cell *const row = ubase + ((4u * m + (e >> 2)) * LDX_UNIT_PAIRS + (e & 3) * kSlab);   // scalar
+#pragma unroll
+                            for (int tt = 0; tt < 4; ++tt) row[lane_off + 32u * tt] = cell[m * 4 + tt];
+                        }
+                    }
+                    const unsigned long long parked = __ballot(!sure);
+                    if (parked) {   // wave-uniform
+                        const uint32_t np = (uint32_t)__builtin_popcountll(parked);
+                        if (qn + np > kQueueCap) {   // more than the queue holds: the fp64 epilogue redoes the unit
+                            LDX_COUNT(2, 1);
+                            return false;
+                        }
+                        if (!sure) {
+                            const uint32_t pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(parked >> 32),
+                                                                              __builtin_amdgcn_mbcnt_lo((uint32_t)parked, 0u));
+                            qid[pos] = ((uint32_t)e << 8) | ln;
+                            v4f *dst = reinterpret_cast<v4f *>(qcnt + (size_t)pos * 8u);
+                            dst[0] = v4f{acc[0][0][e], acc[0][1][e], acc[0][2][e], acc[0][3][e]};
+                            dst[1] = v4f{acc[1][0][e], acc[1][1][e], acc[1][2][e], acc[1][3][e]};
+                        }
+                        qn += np;
+                    }
+                }
+                // ---- the parked steps: fp64 tier, one step (8 pairs) per lane ----
+                LDX_COUNT(0, 1);
+                LDX_COUNT(1, qn);
+                if ((ablate & 2048) != 0) qn = 0;   // tuning: skip the drain (results wrong)
+                if (qn) {
+                    __builtin_amdgcn_s_waitcnt(0xC07F);   // this wave's queue writes have landed (lgkmcnt(0))
+                    __builtin_amdgcn_wave_barrier();
+                }
+                for (uint32_t q0 = 0; q0 < qn; q0 += 64u) {   // wave-uniform
+                    if (q0 + lane < qn) {
+                        const uint32_t id = qid[q0 + lane];
+                        const uint32_t e2 = id >> 8, l2 = id & 31u, h2 = (id >> 5) & 1u;
+                        const v4f *src = reinterpret_cast<const v4f *>(qcnt + (size_t)(q0 + lane) * 8u);
+                        const v4f c0 = src[0], c1 = src[1];
+                        const float cq[2][4] = {{c0.x, c0.y, c0.z, c0.w}, {c1.x, c1.y, c1.z, c1.w}};
+                        uint32_t ri2[2];
+                        FastRow frk[2];
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) {
+                            ri2[m] = 32u * m + (e2 & 3u) + 8u * (e2 >> 2) + 4u * h2;
+                            const d2 *rs = reinterpret_cast<const d2 *>(rstat + ri2[m] * kStat);
+                            const d2 r01 = rs[0], r23 = rs[1];
+                            frk[m] = FastRow{r01.x, r01.y, r23.x, r23.y};
+                        }
+#pragma unroll
+                        for (int tt = 0; tt < 4; ++tt) {
+                            const uint32_t cl = 32u * tt + l2;
+                            const d2 *cs = reinterpret_cast<const d2 *>(cstat + cl * kStat);
+                            const d2 c01 = cs[0], c23 = cs[1];
+                            const FastCol fcx[2] = {FastCol{c01.x, c01.y, c23.x, c23.y}, FastCol{c01.x, c01.y, c23.x, c23.y}};
+                            const float a2[2] = {cq[0][tt], cq[1][tt]};
+                            Cell r2[2];
+                            bool s2[2];
+                            ld_multi_fast2<2, true, Cell>(a2, fk, frk, fcx, r2, s2);
+#pragma unroll
+                            for (int m = 0; m < 2; ++m) {
+                                if (s2[m]) {   // near a rounding tie, Dn == 0: the exact mirror
+                                    const uint32_t i = row0 + ri2[m], j = t * kSlab + cl;
+                                    r2[m] = encode_cell<Cell>(ld_pair_mirror((double)a2[m] / n, fa[i], fr[i], q[i], fa[j], fr[j]));
+#ifdef LDX_TUNING
+                                    atomicAdd(&g_dbg[3], 1ull);
+#endif
+                                }
+                                ubase[(size_t)(ri2[m] / kGroup) * LDX_UNIT_PAIRS + (ri2[m] % kGroup) * kSlab + cl] = r2[m];
+                            }
+                        }
+                    }
+                }
+                return true;
+              } else {
+                return false;
+              }
+            };
             // ---- ld_area: thresholded hits instead of a dense result ----
             // Pair (i, j), i > j, pos_i >= pos_j, serves two ordered pairs of the reference's loop:
             //   A: query i, opposing j -- j lies in i's window iff max(0, pos_i - flank) < pos_j     (ld_area.py:174-177)
@@ -861,8 +1062,16 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
             const bool clean = !kRaw && rows_ordinary && (cols_odd[0] | cols_odd[1]) == 0u &&
                                row0 >= (t + 1u) * kSlab && row0 + 32u * MM <= n_snps && (t + 1u) * kSlab <= n_snps &&
                                vv * 8u >= u_begin && vv * 8u + 8u <= u_end;
-            if (clean && !(ablate & 512)) epilogue(std::true_type{});
-            else epilogue(std::false_type{});
+            if constexpr (kF32Tier && MM == 2) {
+                if (clean && !(ablate & 512)) {
+                    if (!epilogue_f32()) epilogue(std::true_type{});   // queue overflow: the whole unit again, fp64
+                } else {
+                    epilogue(std::false_type{});
+                }
+            } else {
+                if (clean && !(ablate & 512)) epilogue(std::true_type{});
+                else epilogue(std::false_type{});
+            }
             if (tid == 0) tickets[parity] = next_ticket;
             if (!(ablate & 16)) __builtin_amdgcn_s_setprio(0);
 #ifdef LDX_TUNING
@@ -906,7 +1115,7 @@ static int acquire_sched(hipStream_t s, uint32_t **sched)
         size_t operator()(const Key &k) const { return std::hash<void *>()((void *)k.s) * 31u + (size_t)k.dev; }
     };
     struct PerDevice {
-        uint32_t (*pool)[2] = nullptr;   // this device's g_sched
+        uint32_t (*pool)[kSchedWords] = nullptr;   // this device's g_sched
         uint32_t next_slot = 0;
         Key owner[kSchedSlots] = {};
     };
@@ -924,7 +1133,7 @@ static int acquire_sched(hipStream_t s, uint32_t **sched)
         if (!pd.pool) {
             void *sym = nullptr;
             LDX_HIP(hipGetSymbolAddress(&sym, HIP_SYMBOL(g_sched)));   // the current device's copy of the symbol
-            pd.pool = reinterpret_cast<uint32_t (*)[2]>(sym);
+            pd.pool = reinterpret_cast<uint32_t (*)[kSchedWords]>(sym);
         }
         const Key key{dev, s};
         auto it = sched_slot.find(key);
@@ -939,7 +1148,7 @@ static int acquire_sched(hipStream_t s, uint32_t **sched)
         }
         *sched = pd.pool[slot];
     }
-    if (fresh) LDX_HIP(hipMemsetAsync(*sched, 0, 2 * sizeof(uint32_t), s));
+    if (fresh) LDX_HIP(hipMemsetAsync(*sched, 0, kSchedWords * sizeof(uint32_t), s));
     return LDX_OK;
 }
 
@@ -949,7 +1158,17 @@ static int launch_mfma(const void *alt, const double *fa, const double *fr, cons
                        uint32_t *out_n11, hipStream_t s)
 {
     const uint32_t nch = n_chunks(n_hap);
-    const size_t lds = 2u * kBBuf + (kSlab + kMfmaWaves * kStatRows) * kStat * sizeof(double) + 32u;
+    const size_t lds = mfma_lds_bytes(kStatRows, kFp4 && !kRaw && !kN11);
+    if (lds > 64u * 1024u) {   // above 64 KiB the dynamic LDS size needs the opt-in attribute: once per device
+        static std::atomic<uint64_t> opted{0};   // one bit per device ordinal, per instantiation
+        int dev = 0;
+        LDX_HIP(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 64 || !((opted.load(std::memory_order_relaxed) >> dev) & 1u)) {
+            LDX_HIP(hipFuncSetAttribute((const void *)triangle_mfma_kernel<kRaw, kN11, false, kFp4, Cell>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            if (dev >= 0 && dev < 64) opted.fetch_or(1ull << dev, std::memory_order_relaxed);
+        }
+    }
     const int cus = device_cus();
     // the range of passes that intersect [unit_begin, unit_end)
     const uint32_t ns = n_slabs(n_snps);
@@ -984,6 +1203,8 @@ static int launch_mfma(const void *alt, const double *fa, const double *fr, cons
     if (grid < 1) grid = 1;
     uint32_t *sched = nullptr;
     if (int rc = acquire_sched(s, &sched)) return rc;
+    AreaArgs tri_args{};
+    tri_args.f32 = f32_const((double)n_hap);
     int ablate = 0;
     unsigned long long *stamps = nullptr;
 #ifdef LDX_TUNING
@@ -997,7 +1218,7 @@ static int launch_mfma(const void *alt, const double *fa, const double *fr, cons
 #endif
     triangle_mfma_kernel<kRaw, kN11, false, kFp4, Cell><<<(uint32_t)grid, kMfmaThreads, lds, s>>>(
         (const uint4 *)alt, fa, fr, q, n_snps, n_slabs(n_snps), nch, (double)n_hap, 1.0 / (double)n_hap, unit_begin,
-        unit_end, out, out_raw, out_n11, p_begin, p_end, n_short, sched, ablate, stamps, AreaArgs{});
+        unit_end, out, out_raw, out_n11, p_begin, p_end, n_short, sched, ablate, stamps, tri_args);
     LDX_HIP(hipGetLastError());
 #ifdef LDX_TUNING
     if (stamps) {   // tuning only: synchronous; the file holds the stamps of the LAST launch
@@ -1110,11 +1331,11 @@ int area_mfma(const void *alt, const double *fa, const double *fr, const double 
     LDX_HIP(hipGetLastError());
     area_band_plan_kernel<<<1, 1024, 0, s>>>(positions, n_snps, T, flank, g_end, pass_base);
     LDX_HIP(hipGetLastError());
-    const size_t lds = 2u * kBBuf + (kSlab + kMfmaWaves * kRows64) * kStat * sizeof(double) + 32u;
+    const size_t lds = mfma_lds_bytes(kRows64, false);
     const int cus = device_cus();
     uint32_t *sched = nullptr;
     if (int rc = acquire_sched(s, &sched)) return rc;
-    AreaArgs aa;
+    AreaArgs aa{};
     aa.pos = positions;
     aa.is_query = is_query;
     aa.pass_base = pass_base;
@@ -1196,5 +1417,17 @@ extern "C" int ldx_probe_mfma_dev(uint32_t *sink, uint32_t blocks, uint32_t thre
 extern "C" int ldx_debug_force_short_passes(int n_short)
 {
     ldx::g_forced_short.store(n_short < 0 ? -1 : n_short, std::memory_order_relaxed);
+    return LDX_OK;
+}
+
+extern "C" int ldx_debug_counters(uint64_t out[8], int reset)
+{
+    LDX_REQUIRE(out, "null pointer");
+    LDX_HIP(hipDeviceSynchronize());
+    LDX_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(ldx::g_dbg), 8 * sizeof(uint64_t)));
+    if (reset) {
+        const uint64_t zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        LDX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(ldx::g_dbg), zero, sizeof(zero)));
+    }
     return LDX_OK;
 }

@@ -158,8 +158,10 @@ __device__ inline bool same_cell<ldx_k16>(const ldx_k16 &a, const ldx_k16 &b)
 // the count-domain fp64 one of the matrix kernels (general variant, and the "clean" variant where it applies; int and
 // float count operands), each with its mirror fallback.  They must agree bit for bit; otherwise the result is poisoned.
 template <typename Cell>
-__device__ inline Cell all_tiers(double n, double rn, uint32_t c11, double fa1, double fr1, double fa2, double fr2, bool &same)
+__device__ inline Cell all_tiers(double n, double rn, uint32_t c11, double fa1, double fr1, double fa2, double fr2, bool &same,
+                                 bool &f32_sure)
 {
+    f32_sure = false;
     const double f11 = div_by_n((double)c11, n, rn);
     const double q1 = fa1 * fr1;
     bool slow;
@@ -197,6 +199,15 @@ __device__ inline Cell all_tiers(double n, double rn, uint32_t c11, double fa1, 
             ld_multi_fast2<1, true, Cell>(cnt_, fk, fr_, fc_, g_, sg_);
             if (sg_[0]) g_[0] = mir;
             same = same && same_cell(g_[0], res);
+            // the fp32 first tier of the FP4 kernel: whenever it calls a pair sure, its cell must be the mirror's
+            const F32Const f32k = f32_const(n);
+            const F32Row r32[1] = {f32_row(fr_[0].a_s * 1e-4, fr_[0].ra, fr_[0].rr)};
+            const F32Col c32[1] = {f32_col(fc_[0].a, fc_[0].ra, fc_[0].rr)};
+            Cell h_[1];
+            float wmax = 0.0f, ymin = 1.0f;
+            ld_multi_f32<1, Cell>(cnt_, f32k, r32, c32, h_, wmax, ymin);
+            f32_sure = (wmax < f32k.tol) & (ymin > 0.0f);
+            if (f32_sure) same = same && same_cell(h_[0], res);
         }
     }
     return res;
@@ -219,19 +230,23 @@ __global__ void ld_from_counts_kernel(double n, double rn, size_t m, const uint3
         kout[2 * k] = round4_k(lr.rsq);
         kout[2 * k + 1] = round4_k(lr.dprime);
     }
+    bool tier = false;
     if (cells32) {
-        bool same;
-        ldx_ld32 res = all_tiers<ldx_ld32>(n, rn, n11[k], fa1, fr1, fa2, fr2, same);
+        bool same, sure32;
+        ldx_ld32 res = all_tiers<ldx_ld32>(n, rn, n11[k], fa1, fr1, fa2, fr2, same, sure32);
         if (!same) res = ldx_ld32{__uint_as_float(0x7FC00000u), __uint_as_float(0x7FC00000u)};
         cells32[k] = res;
+        tier = sure32;
     }
     if (cells16) {
-        bool same;
-        ldx_k16 res = all_tiers<ldx_k16>(n, rn, n11[k], fa1, fr1, fa2, fr2, same);
+        bool same, sure32;
+        ldx_k16 res = all_tiers<ldx_k16>(n, rn, n11[k], fa1, fr1, fa2, fr2, same, sure32);
         if (!same) res = ldx_k16{0xFFFFu, 0xFFFFu};
         cells16[k] = res;
+        tier = sure32;
     }
-    if (flags) flags[k] = (uint8_t)lr.flags;
+    // bit 7 (LDX_FLAG_F32_SURE, reported by this entry point only): the fp32 tier would have kept the pair
+    if (flags) flags[k] = (uint8_t)(lr.flags | (tier ? LDX_FLAG_F32_SURE : 0u));
 }
 
 // ---- LD of an explicit list of pairs: one wavefront per pair, AND + popcount over the chunks of the two rows, the

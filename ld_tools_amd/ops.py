@@ -215,8 +215,8 @@ def ld_from_counts(n: int, n11, a1, r1, a2, r2, device: Optional[torch.device] =
     """The epilogue alone (calc_ld.py:33-97) on arrays of counts.
 
     Returns (raw float64 [m,2], rounded float32 [m,2], flags uint8 [m]) as device tensors; with ``full`` also
-    k (float64 [m,2]: round(x, 4) * 10^4, exact for any magnitude) and the 4-byte cells (int16 [m,2], the bit patterns
-    of ldx_k16).
+    k (float64 [m,2]: round(x, 4) * 10^4, exact for any magnitude), the 4-byte cells (int16 [m,2], the bit patterns
+    of ldx_k16) and a bool [m] telling which pairs the fp32 epilogue tier would have kept (the others go to fp64).
     """
     dev = device or torch.device("cuda", torch.cuda.current_device())
     def up(x):
@@ -232,8 +232,10 @@ def ld_from_counts(n: int, n11, a1, r1, a2, r2, device: Optional[torch.device] =
     check(lib.ldx_ld_from_counts_ex_dev(int(n), m, t11.data_ptr(), ta1.data_ptr(), tr1.data_ptr(), ta2.data_ptr(),
                                         tr2.data_ptr(), raw.data_ptr(), _ptr(k), rnd.data_ptr(), _ptr(k16),
                                         flags.data_ptr(), _stream_ptr()), "ldx_ld_from_counts_ex_dev")
+    sure32 = (flags & 0x80) != 0       # LDX_FLAG_F32_SURE: the fp32 epilogue tier would have kept the pair
+    flags = flags & 3
     if full:
-        return raw, rnd, flags, k, k16
+        return raw, rnd, flags, k, k16, sure32
     return raw, rnd, flags
 
 

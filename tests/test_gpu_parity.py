@@ -200,7 +200,7 @@ def test_epilogue_small_n_exhaustive(gpu, small_n):
     for n in np.unique(counts[:, 0]):
         m = counts[:, 0] == n
         c = counts[m]
-        raw, rnd, flags, k, k16 = ld_from_counts(int(n), c[:, 1], c[:, 2], c[:, 3], c[:, 4], c[:, 5], full=True)
+        raw, rnd, flags, k, k16, sure32 = ld_from_counts(int(n), c[:, 1], c[:, 2], c[:, 3], c[:, 4], c[:, 5], full=True)
         rnd = rnd.cpu().numpy()
         k = k.cpu().numpy()
         assert np.array_equal(k[:, 0], small_n["k_rsq"][m]) and np.array_equal(k[:, 1], small_n["k_dp"][m])   # exact k
@@ -246,8 +246,13 @@ def test_epilogue_random_tuples_at_panel_sizes(gpu, n):
     n11 = np.where(kind == 5, rng.choice([0, 1], m) * hi + (1 - rng.choice([0, 1], m)) * lo, n11)
     n11 = np.clip(n11, np.where(kind == 3, 0, lo), hi)
     arrs = [x.astype(np.uint32) for x in (n11, a1, r1, a2, r2)]
-    raw, rnd, flags, k, k16 = ld_from_counts(n, *arrs, full=True)
+    raw, rnd, flags, k, k16, sure32 = ld_from_counts(n, *arrs, full=True)
     rnd, flags, k = rnd.cpu().numpy(), flags.cpu().numpy(), k.cpu().numpy()
+    # the fp32 tier keeps most ordinary pairs (the rest go to the fp64 tier); whenever it keeps one its cell equals the
+    # others' (checked in the kernel: a disagreement poisons the cell)
+    ordinary = (arrs[1] > 0) & (arrs[2] > 0) & (arrs[3] > 0) & (arrs[4] > 0) & (arrs[1] + arrs[2] == n) & (arrs[3] + arrs[4] == n)
+    sure32 = sure32.cpu().numpy()
+    assert not sure32[~ordinary].any() and sure32[ordinary].mean() > 0.9, sure32[ordinary].mean()
     o_rsq_raw, o_dp_raw, o_rsq, o_dp, o_flags = c_oracle.ld_from_counts_v(n, *arrs, libm_pow=True)
     assert np.array_equal(flags, o_flags)
     # k itself (a double: exact for any magnitude) against the oracle's round(x, 4); k / 1e4 is that very double
@@ -267,7 +272,7 @@ def test_epilogue_kat(gpu, kat):
 
     for item in kat["tuples"]:
         n, n11, a1, r1, a2, r2 = item["counts"]
-        raw, rnd, flags, k, k16 = ld_from_counts(n, [n11], [a1], [r1], [a2], [r2], full=True)
+        raw, rnd, flags, k, k16, _ = ld_from_counts(n, [n11], [a1], [r1], [a2], [r2], full=True)
         e = item["expect"]
         f = int(flags[0])
         # k / 10^4 in double IS the reference's round(x, 4), whatever the magnitude (the D' >> 1 tuples included)
