@@ -1,25 +1,31 @@
 #!/usr/bin/env python3
 """Benchmark of the pairwise-LD hot path on MI355X: SNP-pairs/s producing r^2 + D'.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--snps S] [--haps H]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--snps S] [--haps H] [--fmt k16|ld32] [--path fp4|mfma|popcount]
 
-One "step" = one full pass of the hot path over one synthetic panel that is already resident in HBM
-as packed slab shards: (N > 1: all-gather of the shards over RCCL) -> ld_triangle kernel over this
-rank's share of the pass list -> 8 bytes per pair (float32 r^2, float32 D', 4-decimal) written to HBM.
+One "step" = one full pass of the hot path over one synthetic panel that is already resident in HBM as packed slab
+shards: (N > 1: all-gather of the shards over RCCL) -> ld_triangle kernel over this rank's share of the pass list ->
+one result cell per pair written to HBM (4 bytes: k = round(x, 4) * 10^4 for r^2 and D' as two uint16 -- lossless with
+respect to the reference's rounded output; --fmt ld32 writes the 8-byte float32 pair instead).
 
-Workload (BASELINE.json): N = 1 -> configs[1], ld_triangle 10 000 SNPs x 5008 haplotypes.  N > 1 keeps
-the pairs per GPU constant (weak scaling): S = 10 000 * sqrt(N) SNPs rounded up to whole 128-row slabs,
-row-block shards packed per rank, exchanged by all-gather, unit list split evenly (ld_tools_amd/dist.py).
---snps overrides S (e.g. --snps 100000 for configs[3]).
+Workloads (BASELINE.json): N = 1 -> configs[1], ld_triangle 10 000 SNPs x 5008 haplotypes.  N > 1 -> configs[3],
+100 000 x 5008, a FIXED problem whose pass list is cut into N equal contiguous ranges (strong scaling): row-block
+shards packed per rank, exchanged by ONE all-gather per step, every rank computes its range against the full plane
+(ld_tools_amd/dist.py).  --snps overrides either.
 
-Timing: W warm-up steps, then --settle-steps more untimed steps (the shader clock needs tens of ms of load to
-settle; reported as config.settle_steps), then EXACTLY K steps between barrier + synchronize on both sides, max
-over ranks.  The K steps are replayed as one HIP graph (eager with --no-graph); the output is NaN-filled before the
-timed region and compared bit for bit with a separately computed result after it.
+Launch: `python bench.py --gpus N` with N > 1 starts `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+itself, as a CHILD process and before this process has touched the GPU, relays rank 0's JSON line and exits non-zero
+if the child fails or overruns --deadline; under torch.distributed.run (RANK / WORLD_SIZE set) it runs as a rank.
 
-Prints ONE JSON line on rank 0 (see the driver contract): whole-job pairs/s, ms per step, the roofline
-object of the dominant kernel (HIP events on the launch stream, live) and, at N = 1, the CPU baseline
-(the pure-Python restatement of the reference's list/zip/count algorithm, 1 core, bounded sample).
+Timing: W warm-up steps, then --settle-steps more untimed steps (the shader clock needs tens of ms of load to settle;
+reported as config.settle_steps, and the from-idle figure is reported beside it as cold_ms_per_step), then EXACTLY K
+steps between barrier + synchronize on both sides, max over ranks.  The K steps are replayed as one HIP graph (eager
+with --no-graph; a failed capture falls back to eager, a failed child run is repeated once without the graph); the
+output is poisoned before the timed region and compared bit for bit with a separately computed result after it.
+
+Prints ONE JSON line on rank 0: whole-job pairs/s, ms per step, the roofline object of the dominant kernel (HIP events
+on the launch stream, live), at N = 1 the other two kernel paths on the same workload (int8 MFMA, AND+popcount) and the
+CPU baseline (the pure-Python restatement of the reference's list/zip/count algorithm, 1 core, bounded sample).
 """
 from __future__ import annotations
 
@@ -27,6 +33,8 @@ import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -35,18 +43,22 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-MFMA_I8_PEAK_TOPS = 5000.0                # ... dense I8 MFMA = 2x the BF16 rate per clock = ~5 POP/s (no sparsity)
+MFMA_FP4_PEAK_TOPS = 10000.0              # ... FP4 / FP6 MFMA dense = 4x the BF16 rate per clock = ~10 POP/s (no sparsity)
+MFMA_I8_PEAK_TOPS = 5000.0                # ... I8 MFMA dense = 2x BF16 = ~5 POP/s
 VALU_PEAK_TLANEOPS = 256 * 64 * 2.4e9 / 1e12   # AND / BCNT have no packed form: 64 lanes/clk/CU at 2.4 GHz = 39.3 T
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--snps", type=int, default=0, help="panel size (default: 10000 * sqrt(gpus))")
+    ap.add_argument("--snps", type=int, default=0, help="panel size (default: 10 000 at N = 1, 100 000 at N > 1)")
     ap.add_argument("--haps", type=int, default=5008)
+    ap.add_argument("--fmt", default="k16", choices=("k16", "ld32"),
+                    help="result cells: k16 = 4 bytes per pair (two uint16 k = value * 10^4, lossless), ld32 = 8 bytes (two float32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="N = 1: skip the int8 / popcount / other-format legs")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--force-dist", action="store_true", help="run the sharded path (process group + all-gather) even at world 1")
     ap.add_argument("--cpu-sample-snps", type=int, default=320)
@@ -55,14 +67,61 @@ def parse():
                     help="N > 1: finish each step's all-gather before its kernel instead of overlapping it with the "
                          "previous step's kernel")
     ap.add_argument("--overlap", action="store_true", help="use the overlapped exchange even in a one-rank group (rehearsals)")
-    ap.add_argument("--settle-steps", type=int, default=600,
+    ap.add_argument("--settle-steps", type=int, default=-1,
                     help="untimed steps run right before the timed region, on top of --warmup, so that it starts at "
-                         "sustained clocks (the shader clock needs tens of ms of load to settle; 0 = off)")
+                         "sustained clocks (default: ~0.15 s worth; 0 = off)")
     ap.add_argument("--path", default="auto", choices=("auto", "fp4", "mfma", "popcount"),
-                    help="kernel behind ld_triangle (auto = the int8 MFMA kernel; results are identical)")
-    return ap.parse_args()
+                    help="kernel behind ld_triangle (auto = the FP4 MFMA kernel; results are identical)")
+    ap.add_argument("--deadline", type=float, default=1500.0, help="seconds the launcher waits for the rank processes")
+    ap.add_argument("--pg-timeout", type=float, default=300.0, help="seconds a collective may take before the job aborts")
+    ap.add_argument("--no-single-gpu-leg", action="store_true",
+                    help="N > 1: skip timing the whole workload on rank 0 alone (the strong-scaling reference)")
+    return ap.parse_args(argv)
 
 
+# ------------------------------------------------------------------------------------------ launcher (no GPU use)
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv) -> int:
+    """Start one rank per GPU through torch.distributed.run in a child process and relay rank 0's JSON line.  This
+    process never initialises HIP (an exec or fork after HIP init is what must not happen; a plain child is fine)."""
+    def attempt(extra):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(Path(__file__).resolve())] + argv + extra
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        try:
+            proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=None, text=True, timeout=args.deadline, env=env)
+        except subprocess.TimeoutExpired as exc:
+            print(f"[bench] the rank processes overran the deadline of {args.deadline:.0f} s", file=sys.stderr)
+            out = exc.stdout if isinstance(exc.stdout, str) else (exc.stdout or b"").decode("utf-8", "replace")
+            return 124, out
+        return proc.returncode, proc.stdout or ""
+
+    def json_line(text):
+        for line in reversed(text.splitlines()):
+            if line.startswith("{") and '"metric"' in line:
+                return line
+        return None
+
+    rc, out = attempt([])
+    line = json_line(out)
+    if (rc != 0 or line is None) and not args.no_graph:
+        print(f"[bench] rank processes failed (rc {rc}); once more with eager launches instead of the HIP graph", file=sys.stderr)
+        rc, out = attempt(["--no-graph"])
+        line = json_line(out)
+    if line is None:
+        sys.stdout.write(out)
+        return rc or 1
+    print(line, flush=True)
+    return rc
+
+
+# ------------------------------------------------------------------------------------------ CPU baseline
 def cpu_baseline(codes_host, sample_snps):
     """Time the oracle's pure-Python list/zip/count path (kind "port") on the first rows of the bench panel."""
     from oracle import c_oracle
@@ -121,9 +180,10 @@ def _cpu_model():
     return "unknown"
 
 
-def main():
-    args = parse()
-    import numpy as np
+# ------------------------------------------------------------------------------------------ one rank
+def run_rank(args):
+    import datetime
+
     import torch
     import torch.distributed as dist
 
@@ -131,8 +191,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; there is no CPU path")
@@ -144,25 +202,23 @@ def main():
     if use_dist:
         if "RANK" not in os.environ:                  # --force-dist without a launcher: a one-rank group
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29517")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
             os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+        tmo = datetime.timedelta(seconds=args.pg_timeout)     # a hung exchange aborts the job instead of hanging it
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, timeout=tmo)
 
     from ld_tools_amd import PackedPanel, dist as ldist, ld_triangle, ops, synth
     from ld_tools_amd._lib import lib
 
     ops.set_triangle_path(args.path)
-    mfma = args.path != "popcount"
+    path = "fp4" if args.path == "auto" else args.path
+    fmt = args.fmt
+    cell_bytes = 4 if fmt == "k16" else 8
     n_hap = args.haps
-    if args.snps:
-        n_snps = args.snps
-    elif world == 1:
-        n_snps = 10000                                                   # BASELINE.json configs[1]
-    else:
-        n_snps = int(math.ceil(10000 * math.sqrt(world) / 128.0)) * 128  # constant pairs per GPU
+    n_snps = args.snps or (10000 if world == 1 else 100000)        # BASELINE.json configs[1] / configs[3]
     n_pairs = n_snps * (n_snps - 1) // 2
 
     # ---- setup (untimed): every rank ingests and packs its own row block ----
@@ -175,8 +231,8 @@ def main():
     u0, u1 = ldist.unit_partition(n_snps, world)[rank]
     out = None
     panel = None if use_dist else local
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev_k0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev_k1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
     # N > 1: every step exchanges the packed shards (ONE RCCL all-gather) and runs this rank's share of the kernel.
     # The exchange of step k + 1 is issued before the kernel of step k and finished after it (double-buffered
@@ -196,10 +252,10 @@ def main():
         elif use_dist:
             panel = ldist.all_gather_panel(local, n_snps, n_hap, out=panel)
         if k is not None:
-            ev0[k].record()
-        out = ld_triangle(panel, unit_range=(u0, u1), out=out)
+            ev_k0[k].record()
+        out = ld_triangle(panel, unit_range=(u0, u1), out=out, fmt=fmt)
         if k is not None:
-            ev1[k].record()
+            ev_k1[k].record()
 
     def run_steps(count, timed=False):
         for k in range(count):
@@ -210,12 +266,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed_region(fn):
+        fence()
+        a, c = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        a.record()
+        fn()
+        c.record()
+        fence()
+        return time.perf_counter() - t0, a.elapsed_time(c)
+
     run_steps(args.warmup)
     fence()
-    # The K steps are K back-to-back launches of a 0.25 ms kernel (plus, for N > 1, the exchange's all-gather and a
+    # from-idle figure: the K steps right after the warm-up, before any clock settling (what a short job sees)
+    cold_dt, _ = timed_region(lambda: run_steps(args.steps))
+    # The K steps are K back-to-back launches of a ~0.15 ms kernel (plus, for N > 1, the exchange's all-gather and a
     # handful of small copies): a launch-bound inner loop, captured once into a HIP graph and replayed inside the
-    # timed region.  The kernel's duration is then (graph span - exchange share) / K from HIP events on the replay
-    # stream at N = 1; any failure to capture falls back to eager launches.
+    # timed region; any failure to capture falls back to eager launches.
     graph = None
     if not args.no_graph and (not use_dist or args.backend == "nccl"):   # RCCL collectives capture; gloo ones do not
         try:
@@ -229,76 +296,85 @@ def main():
             print(f"[bench] HIP graph capture unavailable ({type(exc).__name__}: {exc}); eager launches", file=sys.stderr)
             graph = None
             torch.cuda.synchronize()
-    # Clock settling (untimed, reported in config): a 20-step timed region is 5 ms, far shorter than the tens of ms the
-    # shader clock takes to settle under load, and would read 15 % slow whatever the launch method.
-    # A fixed step count, not a time, so that every rank issues the same collectives.
+    # Clock settling (untimed, reported in config): a 20-step timed region is a few ms, far shorter than the tens of ms
+    # the shader clock takes to settle under load.  A step COUNT, so every rank issues the same collectives.
+    settle = args.settle_steps
+    if settle < 0:
+        settle = max(args.steps, int(0.15 / max(cold_dt / args.steps, 1e-6)))
+        settle = min(settle, 2000)
+        if use_dist:                        # every rank must run the same number of collectives
+            t = torch.tensor([settle], dtype=torch.int64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            settle = int(t.item())
     settle_done = 0
-    if args.settle_steps > 0:
+    if settle > 0:
         if graph is not None:
-            for _ in range((args.settle_steps + args.steps - 1) // args.steps):
+            for _ in range((settle + args.steps - 1) // args.steps):
                 graph.replay()
                 settle_done += args.steps
         else:
-            run_steps(args.settle_steps)
-            settle_done = args.settle_steps
+            run_steps(settle)
+            settle_done = settle
     if out is not None:
-        out.ld32.fill_(float("nan"))       # the timed steps must produce every result again (checked below)
-    fence()
-    t0 = time.perf_counter()
+        out.cells.fill_(-1)                # the timed steps must produce every result again (checked below)
     if graph is not None:
-        ev0[0].record()
-        graph.replay()
-        ev1[0].record()
+        dt, span_ms = timed_region(graph.replay)
+        kern_ms = span_ms / args.steps
     else:
-        run_steps(args.steps, timed=True)
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dt, _ = timed_region(lambda: run_steps(args.steps, timed=True))
+        kern_ms = sum(a.elapsed_time(b_) for a, b_ in zip(ev_k0, ev_k1)) / args.steps
+
+    def allmax(x):
+        if not use_dist or world == 1:
+            return x, x
+        t = torch.tensor([x, -x], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    if graph is not None:
-        kern_ms = ev0[0].elapsed_time(ev1[0]) / args.steps
-    else:
-        kern_ms = sum(a.elapsed_time(b_) for a, b_ in zip(ev0, ev1)) / args.steps
-    if world > 1:
-        t = torch.tensor([kern_ms], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        kern_ms = float(t.item())
+        return float(t[0].item()), -float(t[1].item())
+
+    dt, _ = allmax(dt)
+    cold_dt, _ = allmax(cold_dt)
+    kern_ms_max, kern_ms_min = allmax(kern_ms)
 
     # the output of the timed region against a separately computed result: nothing was skipped or left stale
-    check = ld_triangle(panel, unit_range=(u0, u1))
+    check = ld_triangle(panel, unit_range=(u0, u1), fmt=fmt)
     torch.cuda.synchronize()
-    if not torch.equal(check.ld32.view(torch.int32), out.ld32.view(torch.int32)):
+    if not torch.equal(check.cells.view(torch.int32), out.cells.view(torch.int32)):
         raise SystemExit("bench.py: the timed steps did not reproduce the triangle (stale or skipped work)")
     del check
 
     value = n_pairs * args.steps / dt
     # ---- roofline of the dominant kernel, per launch, this rank's share ----
     my_pairs = n_pairs / world
-    kern_s = kern_ms * 1e-3
-    alg_bytes = 8.0 * my_pairs + lib.ldx_plane_bytes(n_snps, n_hap)     # 8 B/pair out + the ALT plane read once
-    alg_ops = 2.0 * n_hap * my_pairs                                    # int8 multiply-adds x 2 (2*H per pair)
+    kern_s = kern_ms_max * 1e-3
+    alg_bytes = float(cell_bytes) * my_pairs + lib.ldx_plane_bytes(n_snps, n_hap)   # result cells + the ALT plane read once
+    alg_ops = 2.0 * n_hap * my_pairs                                    # multiply-adds x 2 (2*H per pair)
     lane_ops = 2.0 * math.ceil(n_hap / 32) * my_pairs                   # v_and_b32 + v_bcnt_u32_b32 per 32 haplotypes
-    traffic = None
+    traffic, traffic_src = None, None
     tfile = ROOT / "profiles" / "traffic.json"
     if tfile.exists():
         try:
             rec = json.loads(tfile.read_text())
             if (rec.get("workload") == f"ld_triangle {n_snps}x{n_hap}" and rec.get("gpus") == world
-                    and rec.get("path", "mfma") == ("mfma" if mfma else "popcount")):
+                    and rec.get("path") == path and rec.get("fmt") == fmt):
                 traffic = rec.get("hbm_bytes_per_launch")
+                traffic_src = f"profiles/traffic.json ({rec.get('profile', '?')}; rocprofv3 PMC, not measured in this run)"
         except (ValueError, OSError):
             pass
     hbm = {"bound": "hbm", "achieved": alg_bytes / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "frac": alg_bytes / kern_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": alg_bytes}
-    if mfma:   # the counting runs on the matrix pipe: that ceiling governs (5 POP/s / 10 016 ops = 5.0e11 pairs/s)
-        roofline = {"bound": "mfma", "achieved": alg_ops / kern_s / 1e12, "peak": MFMA_I8_PEAK_TOPS, "unit": "TFLOP/s",
-                    "frac": alg_ops / kern_s / 1e12 / MFMA_I8_PEAK_TOPS, "traffic": traffic,
-                    "kernel": "triangle_mfma_kernel", "kernel_ms": kern_ms, "algorithmic_ops": alg_ops,
-                    "ops_per_pair": 2 * n_hap, "note": "int8 multiply-adds counted as 2 ops (integer, not floating point)"}
+           "frac": alg_bytes / kern_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+           "algorithmic_bytes": alg_bytes}
+    if path in ("fp4", "mfma"):   # the counting runs on the matrix pipe: that ceiling governs
+        peak = MFMA_FP4_PEAK_TOPS if path == "fp4" else MFMA_I8_PEAK_TOPS
+        roofline = {"bound": "mfma", "achieved": alg_ops / kern_s / 1e12, "peak": peak, "unit": "TOP/s",
+                    "frac": alg_ops / kern_s / 1e12 / peak, "traffic": traffic, "traffic_source": traffic_src,
+                    "kernel": "triangle_mfma_kernel", "kernel_ms": kern_ms_max, "kernel_ms_min_rank": kern_ms_min,
+                    "algorithmic_ops": alg_ops, "ops_per_pair": 2 * n_hap,
+                    "pipe": ("v_mfma_f32_32x32x64_f8f6f4, FP4 operands (dense peak 10 POP/s)" if path == "fp4"
+                             else "v_mfma_i32_32x32x32_i8 (dense peak 5 POP/s)"),
+                    "frac_of_int8_peak": alg_ops / kern_s / 1e12 / MFMA_I8_PEAK_TOPS,
+                    "note": "multiply-adds counted as 2 ops; 0/1 operands, exact integer result"}
     else:
-        roofline = dict(hbm, kernel="triangle_kernel", kernel_ms=kern_ms)
+        roofline = dict(hbm, kernel="triangle_kernel", kernel_ms=kern_ms_max)
     line = {
         "metric": "SNP-pairs/sec (r2+D')",
         "value": value,
@@ -307,28 +383,88 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
+        "cold_ms_per_step": cold_dt / args.steps * 1e3,     # the same K steps from idle clocks, eager launches
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "int8" if mfma else "u32",
+        "dtype": {"fp4": "fp4 (E2M1 0/1 operands, exact f32 accumulation)", "mfma": "int8", "popcount": "u32"}[path],
         "data": "synthetic",
         "config": {"workload": f"ld_triangle {n_snps}x{n_hap}", "n_snps": n_snps, "n_hap": n_hap,
-                   "pairs_per_step": n_pairs, "output": "8 B/pair (f32 r2, f32 D', rounded to 4 decimals) in HBM",
-                   "kernel_path": "int8 MFMA counts + f64 epilogue" if mfma else "AND+popcount counts + f64 epilogue",
+                   "pairs_per_step": n_pairs,
+                   "output": ("4 B/pair in HBM: uint16 k = round(x, 4) * 10^4 for r2 and D' (lossless)" if fmt == "k16"
+                              else "8 B/pair in HBM: float32 r2, float32 D', rounded to 4 decimals"),
+                   "kernel_path": {"fp4": "FP4 MFMA counts + fp32 / fp64 / mirror epilogue tiers",
+                                   "mfma": "int8 MFMA counts + fp64 epilogue",
+                                   "popcount": "AND+popcount counts + fp64 epilogue"}[path],
                    "launch": "HIP graph of the K steps, output verified after the timed region" if graph is not None else "eager",
                    "settle_steps": settle_done,   # untimed, beyond --warmup: the timed region starts at sustained clocks
                    "sharding": "none" if world == 1 else f"row-block shards, all-gather, pass list / {world}",
+                   "rccl_ranks": dist.get_world_size() if use_dist else 1,
+                   "backend": args.backend if use_dist else None,
                    "exchange": ("none" if not use_dist else "per step, overlapped with the previous step's kernel"
                                 if pipe is not None else "per step, before the kernel")},
         "roofline": roofline,
-        "roofline_hbm": hbm,      # the metric's "% HBM roofline": output bytes + one read of the packed plane
+        "roofline_hbm": hbm,      # the metric's "% HBM roofline": result bytes + one read of the packed plane
     }
-    if not mfma:   # the popcount path is bound by the integer VALU, not by HBM
+    if path == "popcount":   # the popcount path is bound by the integer VALU, not by HBM
         line["roofline_valu"] = {"bound": "valu-int", "achieved": lane_ops / kern_s / 1e12, "peak": VALU_PEAK_TLANEOPS,
                                  "unit": "T lane-ops/s", "frac": lane_ops / kern_s / 1e12 / VALU_PEAK_TLANEOPS,
                                  "ops_per_pair": 2 * math.ceil(n_hap / 32)}
     if graph is not None and use_dist:   # the graph's span is all there is: the exchange rides in the per-step figure
         roofline["kernel_ms_includes_exchange"] = True
+    elif use_dist:                       # eager: exchange = step time minus the kernel's own events
+        line["config"]["exchange_ms_per_step"] = max(0.0, dt / args.steps * 1e3 - kern_ms_max)
+
+    def leg(leg_path, leg_fmt, reps):
+        """Another kernel path / cell format on the same resident panel (N = 1), eager launches at settled clocks."""
+        res = ld_triangle(panel, fmt=leg_fmt, path=leg_path)
+        for _ in range(max(3, reps // 4)):
+            ld_triangle(panel, out=res, fmt=leg_fmt, path=leg_path)
+        torch.cuda.synchronize()
+        a, c = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            ld_triangle(panel, out=res, fmt=leg_fmt, path=leg_path)
+        c.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(c) / reps
+        o = {"ms": ms, "pairs_per_s": n_pairs / (ms * 1e-3), "fmt": leg_fmt}
+        if leg_path == "popcount":
+            o["frac_of_valu_int_peak"] = lane_ops / (ms * 1e-3) / 1e12 / VALU_PEAK_TLANEOPS
+        else:
+            o["frac_of_pipe_peak"] = alg_ops / (ms * 1e-3) / 1e12 / (MFMA_FP4_PEAK_TOPS if leg_path == "fp4" else MFMA_I8_PEAK_TOPS)
+        return o
+
+    if world == 1 and not use_dist and not args.no_extra_legs:
+        # north_star: "MFMA only if ... proves faster than the popcount path" -- all three on the driver-run record
+        reps = max(10, min(args.steps, 100))
+        other = "ld32" if fmt == "k16" else "k16"
+        line["other_paths"] = {f"fp4_{other}": leg("fp4", other, reps),
+                               "mfma_int8": leg("mfma", fmt, reps),
+                               "popcount": leg("popcount", fmt, max(5, reps // 4))}
+    if world > 1 and not args.no_single_gpu_leg:
+        # strong-scaling reference: the WHOLE workload on rank 0's GPU alone, a few steps (the other ranks wait)
+        single = None
+        if rank == 0:
+            try:
+                res1 = ld_triangle(panel, fmt=fmt)
+                torch.cuda.synchronize()
+                a, c = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(3):
+                    ld_triangle(panel, out=res1, fmt=fmt)
+                c.record()
+                torch.cuda.synchronize()
+                ms1 = a.elapsed_time(c) / 3
+                single = {"ms_per_step": ms1, "pairs_per_s": n_pairs / (ms1 * 1e-3)}
+                del res1
+            except Exception as exc:   # noqa: BLE001  (an extra: e.g. not enough memory for the whole triangle)
+                single = {"error": f"{type(exc).__name__}: {exc}"}
+        dist.barrier()
+        if rank == 0:
+            line["config"]["single_gpu_same_workload"] = single
+            if single and "pairs_per_s" in single:
+                line["config"]["speedup_over_one_gpu"] = value / single["pairs_per_s"]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         need = max(args.cpu_sample_snps, 1536)
         host = codes_local[:need].cpu().numpy()
@@ -337,6 +473,14 @@ def main():
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse(argv)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args, argv))
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -24,3 +24,25 @@ def test_two_ranks_one_card_sharded_triangle():
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=500, env=env, cwd=str(ROOT))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "GPU_DIST_OK" in r.stdout
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks():
+    """The driver's command line, `python bench.py --gpus N`, without torch.distributed.run around it: the launcher starts
+    the ranks as a child process and relays rank 0's line.  Two ranks share the one card here (gloo); the panel is small."""
+    import json
+
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--snps", "3000",
+                        "--backend", "gloo", "--settle-steps", "0", "--deadline", "400"], capture_output=True, text=True,
+                       timeout=500, env=env, cwd=str(ROOT))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and rec["config"]["rccl_ranks"] == 2
+    assert rec["config"]["workload"] == "ld_triangle 3000x5008" and rec["value"] > 0
+    assert rec["config"]["single_gpu_same_workload"]["pairs_per_s"] > 0
+    assert rec["roofline"]["kernel_ms"] >= rec["roofline"]["kernel_ms_min_rank"] > 0

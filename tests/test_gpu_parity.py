@@ -524,6 +524,109 @@ def test_triangle_bench_size_against_oracle_rows(gpu, path):
     rows = np.repeat(np.arange(4096, 4352), 4096)
     cols = np.tile(np.arange(4096), 256)
     assert np.array_equal(n11[res.cell_index(rows, cols)], blk[:, :4096].ravel())
+    # the product variants (no n11 output: on the FP4 path that is the fp32 epilogue tier with its fp64 / mirror fallbacks)
+    # give the very same cells, in both formats
+    import torch
+    plain = ld_triangle(p)
+    assert torch.equal(plain.ld32.view(torch.int32), res.ld32.view(torch.int32))
+    k16 = ld_triangle(p, fmt="k16").k16.cpu().numpy().view(np.uint16).astype(np.int64)
+    want = np.where(np.signbit(ld32), 0x8000, k_of(ld32))
+    assert np.array_equal(k16, want)
+
+
+def _config_panel(n, h):
+    from ld_tools_amd import PackedPanel, synth
+    codes_d = synth.synth_codes_device(n, h, seed=synth.BENCH_SEED)
+    return codes_d, PackedPanel.from_codes(codes_d)
+
+
+def test_config4_triangle_50k_x_1008(gpu):
+    """BASELINE configs[4]: ld_triangle 50 000 SNPs x 1008 haplotypes (EUR-size sub-panel) at full size.  The three kernels
+    agree bit for bit on all 1.25e9 pairs (both cell formats), bands of rows match the C oracle, and the n11 mass equals
+    sum_h C(k_h, 2)."""
+    import torch
+    from ld_tools_amd import ld_triangle
+    from oracle import c_oracle
+
+    n, h = 50000, 1008
+    codes_d, p = _config_panel(n, h)
+    ref = ld_triangle(p, want_n11=True, path="fp4")
+    for other in ("popcount", "mfma"):
+        b = ld_triangle(p, want_n11=True, path=other)
+        assert torch.equal(ref.n11, b.n11), other
+        assert torch.equal(ref.ld32.view(torch.int32), b.ld32.view(torch.int32)), other
+        del b
+    plain = ld_triangle(p, path="fp4")                       # the product variant: fp32 tier + fallbacks
+    assert torch.equal(plain.ld32.view(torch.int32), ref.ld32.view(torch.int32))
+    del plain
+    k16 = ld_triangle(p, fmt="k16", path="fp4")
+    k_ref = torch.where(torch.signbit(ref.ld32), torch.full_like(ref.ld32, 32768.0), torch.round(ref.ld32.double() * 1e4).float())
+    assert torch.equal(k16.k16.to(torch.int32) & 0xFFFF, k_ref.to(torch.int32))
+    for other in ("popcount", "mfma"):
+        b = ld_triangle(p, fmt="k16", path=other)
+        assert torch.equal(b.k16, k16.k16), other
+        del b
+    del k16, k_ref
+    codes = codes_d.cpu().numpy()
+    o = c_oracle.Panel(codes)
+    assert np.array_equal(p.alt_counts(), o.acnt) and np.array_equal(p.ref_counts(), o.rcnt)
+    checked = 0
+    for (r0, r1) in [(1, 30), (25000, 25008), (49996, 50000)]:
+        t = o.triangle(r0, r1, libm_pow=True)
+        rows = np.concatenate([np.full(i, i, dtype=np.int64) for i in range(r0, r1)])
+        cols = np.concatenate([np.arange(i, dtype=np.int64) for i in range(r0, r1)])
+        idx = torch.from_numpy(ref.cell_index(rows, cols)).to(ref.ld32.device)
+        ld32 = ref.ld32[idx].cpu().numpy()
+        assert np.array_equal(ref.n11[idx].cpu().numpy().view(np.uint32), t["n11"][rows, cols])
+        assert np.array_equal(k_of(ld32[:, 0]), np.rint(t["rsq_rnd"][rows, cols] * 1e4).astype(np.int64))
+        assert np.array_equal(k_of(ld32[:, 1]), np.rint(t["dp_rnd"][rows, cols] * 1e4).astype(np.int64))
+        assert np.array_equal(flags_of(ld32), t["flags"][rows, cols])
+        checked += len(rows)
+    assert checked > 400000
+    colsum = (codes == 1).sum(axis=0).astype(np.int64)
+    assert int(ref.n11.to(torch.int64).sum().item()) == int((colsum * (colsum - 1) // 2).sum())
+
+
+def test_config2_area_100k_500kb(gpu):
+    """BASELINE configs[2]: ld_area over a 100 000-SNP chromosome (positions 1 + 500 i: +-500 kb = +-1000 neighbours), every
+    SNP a query, rounded r^2 >= 0.8.  The matrix-pipe band (FP4 and int8) and the popcount scan return the same hits;
+    the hits of three query bands (first, middle, last 200 queries) equal the C oracle's window loop; the number of
+    evaluated pairs equals the window populations."""
+    from ld_tools_amd import ld_area, ops, synth
+    from oracle import c_oracle
+
+    n, h, flank = 100000, 5008, 500000
+    codes_d, p = _config_panel(n, h)
+    pos = synth.synth_positions(n, step=500)
+    got = {}
+    try:
+        for path in ("fp4", "mfma", "popcount"):
+            ops.set_area_path(path)
+            hits = ld_area(p, pos, None, flank, "r_square", 0.8)
+            got[path] = (hits.query.cpu().numpy(), hits.oppos.cpu().numpy(), hits.ld32.cpu().numpy().view(np.uint32), hits.n_pairs)
+    finally:
+        ops.set_area_path("auto")
+    a = got["fp4"]
+    for other in ("mfma", "popcount"):
+        b = got[other]
+        assert len(a[0]) == len(b[0]) and a[3] == b[3], other
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), other
+    # window populations: max(0, pos - flank) < pos_o <= pos + flank (pysam's half-open fetch, ld_area.py:174-177): 999
+    # neighbours below (the SNP exactly 500 kb below is outside), 1000 above, clipped at the chromosome ends
+    idx = np.arange(n)
+    assert a[3] == int((np.minimum(idx, 999) + np.minimum(n - 1 - idx, 1000)).sum())
+    assert len(a[0]) > 100000                                   # the block-LD panel has plenty of r^2 >= 0.8 pairs
+    codes = codes_d.cpu().numpy()
+    o = c_oracle.Panel(codes)
+    for q0 in (0, 49900, n - 200):
+        qs = np.arange(q0, q0 + 200)
+        hq, ho, hr, hd, hf = o.area(pos, qs, flank, 0, 0.8, libm_pow=True)
+        m = (a[0] >= q0) & (a[0] < q0 + 200)
+        assert np.array_equal(a[0][m], hq) and np.array_equal(a[1][m], ho), q0
+        ld = a[2][m].view(np.float32).reshape(-1, 2)
+        assert np.array_equal(k_of(ld[:, 0]), np.rint(hr * 1e4).astype(np.int64)), q0
+        assert np.array_equal(k_of(ld[:, 1]), np.rint(hd * 1e4).astype(np.int64)), q0
+        assert np.array_equal(flags_of(ld), hf), q0
 
 
 def test_triangle_random_shapes_both_kernels_and_oracle(gpu):
