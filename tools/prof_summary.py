@@ -36,7 +36,7 @@ for tag in ("pmc_fetch", "pmc_write", "pmc_sq"):
     if acc:
         print(f"== {tag} (per dispatch mean) ==")
         for k, cs in acc.items():
-            if "triangle" not in k and "pack" not in k:
+            if "triangle" not in k and "pack" not in k and "area" not in k:
                 continue
             print(k[:90])
             for c, v in cs.items():

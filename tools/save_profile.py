@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Copy the judged evidence of one tools/gpu_prof.sh run from gpurun_out/ (scratch) into profiles/ (tracked).
 
-    python tools/save_profile.py <tag> <round-dir> <workload> [path] [gpus]     e.g.  r01b r01 "ld_triangle 10000x5008"
+    python tools/save_profile.py <tag> <round-dir> <workload> [path] [gpus] [fmt] [--no-traffic]
+    e.g.  r02a r02 "ld_triangle 10000x5008" fp4 1 k16      (writes profiles/traffic.json unless --no-traffic)
 """
 import glob
 import json
@@ -10,9 +11,11 @@ import sys
 from pathlib import Path
 
 root = Path(__file__).resolve().parent.parent
-tag, rnd, workload = sys.argv[1], sys.argv[2], sys.argv[3]
-path = sys.argv[4] if len(sys.argv) > 4 else "mfma"
-gpus = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+argv = [a for a in sys.argv if a != "--no-traffic"]
+tag, rnd, workload = argv[1], argv[2], argv[3]
+path = argv[4] if len(argv) > 4 else "fp4"
+gpus = int(argv[5]) if len(argv) > 5 else 1
+fmt = argv[6] if len(argv) > 6 else "k16"
 src = root / "gpurun_out" / f"prof_{tag}"
 dst = root / "profiles" / rnd
 dst.mkdir(parents=True, exist_ok=True)
@@ -22,7 +25,13 @@ for f in glob.glob(str(src / "trace" / "**" / "*kernel_stats.csv"), recursive=Tr
 for line in open(src / "bench_trace.log"):
     if line.startswith("{"):
         (dst / f"{tag}_bench_under_rocprof.json").write_text(line)
-rec = json.loads((src / "traffic_counters.json").read_text())
-rec.update(workload=workload, gpus=gpus, path=path, source=f"profiles/{rnd}/{tag}_rocprofv3_summary.txt")
-(root / "profiles" / "traffic.json").write_text(json.dumps(rec, indent=1) + "\n")
-print(json.dumps(rec))
+if (src / "command.txt").exists():
+    shutil.copy(src / "command.txt", dst / f"{tag}_command.txt")
+if (src / "traffic_counters.json").exists():
+    rec = json.loads((src / "traffic_counters.json").read_text())
+    rec.update(workload=workload, gpus=gpus, path=path, fmt=fmt, profile=tag,
+               source=f"profiles/{rnd}/{tag}_rocprofv3_summary.txt")
+    (dst / f"{tag}_traffic.json").write_text(json.dumps(rec, indent=1) + "\n")
+    if "--no-traffic" not in sys.argv:
+        (root / "profiles" / "traffic.json").write_text(json.dumps(rec, indent=1) + "\n")
+    print(json.dumps(rec))
