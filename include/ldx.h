@@ -211,6 +211,18 @@ int ldx_area_dev(const void *alt, const double *fa, const double *fr, const doub
                  double thres, ldx_hit *hits, uint64_t hit_cap, uint64_t *n_hits, void *workspace,
                  size_t workspace_bytes, void *stream);
 size_t ldx_area_workspace_bytes(uint32_t n_snps, uint32_t n_hap, uint32_t n_query);
+/* Finish a scan on the device, without a host round trip: raw slots (arbitrary order, unused slots marked) -> hits
+ * sorted by (query row, opposing row) = the reference's output order (ld_area.py:152,215-217), plus the per-row index
+ * offsets[n_snps + 1] (hits of query row q are sorted[offsets[q] .. offsets[q + 1])).  n_reserved: the device counter
+ * ldx_area_dev filled; sorted: capacity hit_cap; summary: device uint64 [2] = {number of hits, slots reserved}.
+ * If summary[1] > hit_cap the scan overflowed its buffer: run both again with hit_cap >= summary[1]. */
+int ldx_area_finish_dev(const ldx_hit *raw, const uint64_t *n_reserved, uint64_t hit_cap, uint32_t n_snps,
+                        ldx_hit *sorted, uint32_t *offsets, uint64_t *summary, void *workspace,
+                        size_t workspace_bytes, void *stream);
+size_t ldx_area_finish_workspace_bytes(uint32_t n_snps);
+/* instrumentation: byte offset, inside the workspace of ldx_area_dev, of the uint32 count of passes (4 units of 64 rows
+ * x 128 columns) the matrix-pipe band evaluated */
+size_t ldx_area_band_passes_offset(uint32_t n_snps);
 /* kernel behind ldx_area_dev: LDX_PATH_AUTO (FP4 matrix-pipe band when >= 1/16 of the SNPs are queries, popcount scan
  * otherwise), LDX_PATH_POPCOUNT, LDX_PATH_MFMA (int8 band), LDX_PATH_FP4; the hit sets are identical */
 int ldx_set_area_path(int path);

@@ -105,6 +105,9 @@ SIGNATURES = {
     "ldx_area_dev": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _u32, _i64, _int, _dbl, _vp, _u64,
                             _vp, _vp, _sz, _vp]),
     "ldx_area_workspace_bytes": (_sz, [_u32, _u32, _u32]),
+    "ldx_area_finish_dev": (_int, [_vp, _vp, _u64, _u32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ldx_area_finish_workspace_bytes": (_sz, [_u32]),
+    "ldx_area_band_passes_offset": (_sz, [_u32]),
     "ldx_set_area_path": (_int, [_int]),
     "ldx_get_area_path": (_int, []),
     "ldx_synth_codes_dev": (_int, [_vp, _u32, _u32, _sz, _u64, _vp, _u64, _u32, _u64, _u32, _vp]),

@@ -222,9 +222,130 @@ area_scan_kernel(const uint4 *__restrict__ alt, const uint4 *__restrict__ qalt, 
         if (s < hit_cap) hits[s].query = kInvalid;
 }
 
+// ---- finishing on the device: raw slots (arbitrary order, with unused slots) -> hits in (query, opposing) order ----
+// count per query -> exclusive scan (the CSR row index of the result) -> scatter -> per-query ordering by opposing row.
+// No host round trip: the launches cover the whole slot buffer and read the reserved count from device memory.
+__global__ void area_count_kernel(const ldx_hit *__restrict__ raw, const unsigned long long *__restrict__ n_reserved,
+                                  uint64_t cap, uint32_t n_snps, uint32_t *__restrict__ counts)
+{
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t lim = *n_reserved < cap ? *n_reserved : cap;
+    if (s >= lim) return;
+    const uint32_t qv = raw[s].query;
+    if (qv < n_snps) atomicAdd(&counts[qv], 1u);   // kInvalid marks an unused slot
+}
+
+// single workgroup: offsets[k] = sum of counts[0..k), offsets[n_snps] = all hits; cursor = a copy for the scatter;
+// summary = {hits, slots reserved} (slots reserved > capacity: the caller retries with a larger buffer)
+__global__ void __launch_bounds__(1024) area_offsets_kernel(const uint32_t *__restrict__ counts, uint32_t n_snps,
+                                                            uint32_t *__restrict__ offsets, uint32_t *__restrict__ cursor,
+                                                            const unsigned long long *__restrict__ n_reserved,
+                                                            unsigned long long *__restrict__ summary)
+{
+    __shared__ uint32_t carry;
+    __shared__ uint32_t wsum[16];
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t k0 = 0; k0 < n_snps; k0 += 1024u) {
+        const uint32_t k = k0 + threadIdx.x;
+        const uint32_t c = k < n_snps ? counts[k] : 0u;
+        uint32_t x = c;
+        const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(x, off); if (lane >= (uint32_t)off) x += y; }
+        if (lane == 63) wsum[wv] = x;
+        __syncthreads();
+        uint32_t pre = 0;
+        for (uint32_t w = 0; w < wv; ++w) pre += wsum[w];
+        const uint32_t incl = carry + pre + x;
+        if (k < n_snps) {
+            offsets[k] = incl - c;
+            cursor[k] = incl - c;
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        offsets[n_snps] = carry;
+        summary[0] = carry;
+        summary[1] = *n_reserved;
+    }
+}
+
+__global__ void area_scatter_kernel(const ldx_hit *__restrict__ raw, const unsigned long long *__restrict__ n_reserved,
+                                    uint64_t cap, uint32_t n_snps, uint32_t *__restrict__ cursor, ldx_hit *__restrict__ sorted)
+{
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t lim = *n_reserved < cap ? *n_reserved : cap;
+    if (s >= lim) return;
+    const ldx_hit h = raw[s];
+    if (h.query < n_snps) sorted[atomicAdd(&cursor[h.query], 1u)] = h;
+}
+
+// one thread per query: its hits (a handful) into ascending opposing row = VCF order (ld_area.py:215-217)
+__global__ void area_order_kernel(const uint32_t *__restrict__ offsets, uint32_t n_snps, ldx_hit *__restrict__ sorted)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_snps) return;
+    const uint32_t b = offsets[k], e = offsets[k + 1u];
+    for (uint32_t i = b + 1u; i < e; ++i) {   // insertion sort: segments are short and arrive nearly ordered
+        const ldx_hit h = sorted[i];
+        uint32_t j = i;
+        while (j > b && sorted[j - 1u].oppos > h.oppos) {
+            sorted[j] = sorted[j - 1u];
+            --j;
+        }
+        sorted[j] = h;
+    }
+}
+
 }  // namespace ldx
 
 using namespace ldx;
+
+extern "C" size_t ldx_area_finish_workspace_bytes(uint32_t n_snps)
+{
+    return 2u * (((size_t)n_snps + 1u) * 4u + 255u) / 256u * 256u;   // counts, cursor
+}
+
+extern "C" int ldx_area_finish_dev(const ldx_hit *raw, const uint64_t *n_reserved, uint64_t hit_cap, uint32_t n_snps,
+                                   ldx_hit *sorted, uint32_t *offsets, uint64_t *summary, void *workspace,
+                                   size_t workspace_bytes, void *stream)
+{
+    LDX_REQUIRE(n_reserved && offsets && summary && workspace, "null pointer");
+    LDX_REQUIRE((raw && sorted) || hit_cap == 0, "hit buffers are null but hit_cap > 0");
+    LDX_REQUIRE(n_snps >= 1 && hit_cap < (1ull << 32), "bad shape");
+    LDX_REQUIRE(workspace_bytes >= ldx_area_finish_workspace_bytes(n_snps), "workspace too small");
+    LDX_REQUIRE(((uintptr_t)workspace & 255u) == 0, "workspace must be 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t vec = (((size_t)n_snps + 1u) * 4u + 255u) / 256u * 256u;
+    uint32_t *counts = (uint32_t *)workspace, *cursor = (uint32_t *)((char *)workspace + vec);
+    LDX_HIP(hipMemsetAsync(counts, 0, ((size_t)n_snps + 1u) * 4u, s));
+    const uint32_t slot_blocks = (uint32_t)((hit_cap + 255u) / 256u);
+    if (slot_blocks) {
+        area_count_kernel<<<slot_blocks, 256, 0, s>>>(raw, (const unsigned long long *)n_reserved, hit_cap, n_snps, counts);
+        LDX_HIP(hipGetLastError());
+    }
+    area_offsets_kernel<<<1, 1024, 0, s>>>(counts, n_snps, offsets, cursor, (const unsigned long long *)n_reserved,
+                                           (unsigned long long *)summary);
+    LDX_HIP(hipGetLastError());
+    if (slot_blocks) {
+        area_scatter_kernel<<<slot_blocks, 256, 0, s>>>(raw, (const unsigned long long *)n_reserved, hit_cap, n_snps, cursor,
+                                                        sorted);
+        LDX_HIP(hipGetLastError());
+        area_order_kernel<<<(n_snps + 255u) / 256u, 256, 0, s>>>(offsets, n_snps, sorted);
+        LDX_HIP(hipGetLastError());
+    }
+    return LDX_OK;
+}
+
+extern "C" size_t ldx_area_band_passes_offset(uint32_t n_snps)
+{
+    // byte offset, inside the workspace of ldx_area_dev, of the uint32 that holds the number of passes the matrix-pipe
+    // band evaluated (4 units of 64 rows x 128 columns each): instrumentation for tests and sharding studies
+    return ((size_t)n_snps + 255u) / 256u * 256u + (size_t)ldx::n_slabs(n_snps) * 4u;
+}
 
 // which kernel runs ld_area: LDX_PATH_AUTO = the matrix-pipe band when at least 1/16 of the SNPs are queries (it
 // evaluates every pair of the band once for both orders, whatever the query list: 0.52 ms at 100k SNPs, +-1000

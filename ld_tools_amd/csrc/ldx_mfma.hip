@@ -201,7 +201,8 @@ struct AreaArgs {
     const int64_t *pos;            // [n_snps] ascending 1-based positions
     const uint8_t *is_query;       // [n_snps] 1 = the SNP is a query
     const uint32_t *pass_base;     // [T + 1] prefix sum of passes per j-tile (pass_base[T] = all passes)
-    const uint32_t *g_end;         // [T] one past the last 64-row group a column of tile t can pair with
+    const uint32_t *g_begin;       // [T] first 64-row group of tile t that can hold a hit (2t unless the queries end before the tile)
+    const uint32_t *g_end;         // [T] one past the last such group
     ldx_hit *hits;
     unsigned long long *n_hits;
     uint64_t hit_cap;
@@ -352,9 +353,10 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
         const bool new_tile = t != t_prev;
         t_prev = t;
         const uint64_t tb = base64(t), te = base64(t + 1u);
-        const uint64_t pass = tb + (uint64_t)(p - pbase(t)) * kMfmaWaves;   // its first unit
-        // triangle: the units of the tile inside [v_begin, v_end); area: the units the window can reach
-        const uint64_t seg_begin = kArea ? tb : (v_begin > tb ? v_begin : tb);
+        // triangle: the units of the tile inside [v_begin, v_end); area: the units [g_begin, g_end) the plan kept for the tile
+        const uint64_t area_first = kArea ? tb + (aa.g_begin[t] - 2u * t) : 0u;
+        const uint64_t pass = (kArea ? area_first : tb) + (uint64_t)(p - pbase(t)) * kMfmaWaves;   // its first unit
+        const uint64_t seg_begin = kArea ? area_first : (v_begin > tb ? v_begin : tb);
         const uint64_t seg_end = kArea ? tb + (aa.g_end[t] > 2u * t ? aa.g_end[t] - 2u * t : 0u) : (v_end < te ? v_end : te);
         // the j-tile's bits for this thread's expansion share.  int8: row tid/2, 8 bytes (tid%2) of each chunk;
         // FP4: row tid%128, the whole 16 bytes of chunk 2b + tid/128 of K-block b (that lane half's chunk)
@@ -1269,12 +1271,16 @@ __global__ void area_mask_kernel(const uint32_t *__restrict__ queries, uint32_t 
     if (k < n_query) is_query[queries[k]] = 1;
 }
 
-// single workgroup: per j-tile the last 64-row group its columns can pair with, then the exclusive scan of the
-// tiles' pass counts
+// single workgroup: per j-tile the range of 64-row groups that can hold a hit, then the exclusive scan of the tiles' pass
+// counts.  A pair (row i, column j), i > j, serves query i and query j; with the queries inside rows [qmin, qmax] (the
+// ascending list's ends: a rank's share of a sharded scan is one contiguous range) a tile whose columns lie outside that
+// range only needs the row groups inside it, and a tile whose columns intersect it needs its whole band.
 __global__ void __launch_bounds__(1024) area_band_plan_kernel(const int64_t *__restrict__ pos, uint32_t n_snps, uint32_t T,
-                                                              int64_t flank, uint32_t *__restrict__ g_end,
-                                                              uint32_t *__restrict__ pass_base)
+                                                              int64_t flank, const uint32_t *__restrict__ queries,
+                                                              uint32_t n_query, uint32_t *__restrict__ g_begin,
+                                                              uint32_t *__restrict__ g_end, uint32_t *__restrict__ pass_base)
 {
+    const uint32_t qmin = queries[0], qmax = queries[n_query - 1u];
     __shared__ uint32_t carry;
     __shared__ uint32_t wsum[16];
     if (threadIdx.x == 0) { carry = 0; pass_base[0] = 0; }
@@ -1287,10 +1293,17 @@ __global__ void __launch_bounds__(1024) area_band_plan_kernel(const int64_t *__r
             const int64_t lim = pos[jlast] + flank;            // rows with pos <= lim can pair with a column of the tile
             uint32_t lo = jlast + 1u, hi = n_snps;             // first row index with pos > lim
             while (lo < hi) { const uint32_t m = (lo + hi) / 2; if (pos[m] > lim) hi = m; else lo = m + 1u; }
-            const uint32_t ge = (lo + kRows64 - 1u) / kRows64;   // lo rows -> groups
+            uint32_t ge = (lo + kRows64 - 1u) / kRows64;   // lo rows -> groups
+            uint32_t gb = 2u * t;
+            if (t * kSlab > qmax || jlast < qmin) {   // no query among the tile's columns: only rows that are queries matter
+                const uint32_t qb = qmin / kRows64, qe = qmax / kRows64 + 1u;
+                gb = gb > qb ? gb : qb;
+                ge = ge < qe ? ge : qe;
+            }
+            if (ge < gb) ge = gb;
+            g_begin[t] = gb;
             g_end[t] = ge;
-            const uint32_t units = ge > 2u * t ? ge - 2u * t : 0u;
-            cnt = (units + kMfmaWaves - 1u) / kMfmaWaves;
+            cnt = (ge - gb + kMfmaWaves - 1u) / kMfmaWaves;
         }
         uint32_t x = cnt;
         const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
@@ -1311,7 +1324,7 @@ __global__ void __launch_bounds__(1024) area_band_plan_kernel(const int64_t *__r
 size_t area_mfma_workspace_bytes(uint32_t n_snps)
 {
     const size_t T = n_slabs(n_snps);
-    return ((size_t)n_snps + 255u) / 256u * 256u + ((T + 1u) * 4u + 255u) / 256u * 256u + (T * 4u + 255u) / 256u * 256u;
+    return ((size_t)n_snps + 255u) / 256u * 256u + ((T + 1u) * 4u + 255u) / 256u * 256u + 2u * ((T * 4u + 255u) / 256u * 256u);
 }
 
 int area_mfma(const void *alt, const double *fa, const double *fr, const double *q, uint32_t n_snps, uint32_t n_hap,
@@ -1325,11 +1338,13 @@ int area_mfma(const void *alt, const double *fa, const double *fr, const double 
     uint32_t *pass_base = (uint32_t *)w;
     w += (((size_t)T + 1u) * 4u + 255u) / 256u * 256u;
     uint32_t *g_end = (uint32_t *)w;
+    w += ((size_t)T * 4u + 255u) / 256u * 256u;
+    uint32_t *g_begin = (uint32_t *)w;
     LDX_HIP(hipMemsetAsync(n_hits, 0, sizeof(uint64_t), s));
     LDX_HIP(hipMemsetAsync(is_query, 0, n_snps, s));
     area_mask_kernel<<<(n_query + 255u) / 256u, 256, 0, s>>>(queries, n_query, is_query);
     LDX_HIP(hipGetLastError());
-    area_band_plan_kernel<<<1, 1024, 0, s>>>(positions, n_snps, T, flank, g_end, pass_base);
+    area_band_plan_kernel<<<1, 1024, 0, s>>>(positions, n_snps, T, flank, queries, n_query, g_begin, g_end, pass_base);
     LDX_HIP(hipGetLastError());
     const size_t lds = mfma_lds_bytes(kRows64, false);
     const int cus = device_cus();
@@ -1339,6 +1354,7 @@ int area_mfma(const void *alt, const double *fa, const double *fr, const double 
     aa.pos = positions;
     aa.is_query = is_query;
     aa.pass_base = pass_base;
+    aa.g_begin = g_begin;
     aa.g_end = g_end;
     aa.hits = hits;
     aa.n_hits = (unsigned long long *)n_hits;

@@ -243,11 +243,14 @@ def ld_from_counts(n: int, n11, a1, r1, a2, r2, device: Optional[torch.device] =
 class AreaHits:
     """Thresholded hits of a windowed scan, sorted by (query row, opposing row) = VCF order."""
 
-    def __init__(self, query: torch.Tensor, oppos: torch.Tensor, ld32: torch.Tensor, n_pairs):
+    def __init__(self, query: torch.Tensor, oppos: torch.Tensor, ld32: torch.Tensor, n_pairs, offsets=None,
+                 band_passes=None):
         self.query = query        # int64 [n]  panel row of var_1 (the query)
         self.oppos = oppos        # int64 [n]  panel row of var_2 (the opposing variant)
         self.ld32 = ld32          # float32 [n, 2]  rounded (r_square, d_prime), -0.0 = int 0
         self._n_pairs = n_pairs   # int, or a callable that counts on first use (bookkeeping only)
+        self.offsets = offsets    # int32 [n_snps + 1] (device): the hits of query row q are [offsets[q], offsets[q + 1])
+        self._band_passes = band_passes
 
     @property
     def n_pairs(self) -> int:
@@ -255,6 +258,14 @@ class AreaHits:
         if callable(self._n_pairs):
             self._n_pairs = self._n_pairs()
         return self._n_pairs
+
+    @property
+    def band_passes(self) -> Optional[int]:
+        """Passes (4 units of 64 rows x 128 columns) the matrix-pipe band evaluated for this call; None for the popcount
+        scan.  Instrumentation: shows how the work of a sharded scan splits."""
+        if callable(self._band_passes):
+            self._band_passes = self._band_passes()
+        return self._band_passes
 
     def __len__(self) -> int:
         return int(self.query.numel())
@@ -286,47 +297,61 @@ def ld_area(panel: PackedPanel, positions, queries: Optional[Sequence[int]] = No
     variants are o != q with max(0, pos_q - flank) < pos_o <= pos_q + flank (pysam's fetch,
     ld_area.py:174-177,215-217); var_1 = query, var_2 = opposing; kept when the rounded
     ``measure`` >= thres (ld_area.py:248).
+
+    Everything up to the ordered hit list runs on the device (scan -> count per query -> scan -> scatter -> per-query
+    order: ldx_area_dev + ldx_area_finish_dev); the host reads two integers at the end to size the result.
     """
     dev = panel.device
-    pos = torch.as_tensor(np.ascontiguousarray(np.asarray(positions, dtype=np.int64))) \
-        if not isinstance(positions, torch.Tensor) else positions
-    pos = pos.to(dev, dtype=torch.int64).contiguous()
+    if isinstance(positions, torch.Tensor):
+        pos = positions.to(dev, dtype=torch.int64).contiguous()
+        if pos.numel() > 1 and bool((pos[1:] < pos[:-1]).any().item()):
+            raise _lib.LdxError("positions must ascend (VCF order): the window search is a binary search")
+    else:
+        pos_h = np.ascontiguousarray(np.asarray(positions, dtype=np.int64))
+        if pos_h.size > 1 and bool((pos_h[1:] < pos_h[:-1]).any()):
+            raise _lib.LdxError("positions must ascend (VCF order): the window search is a binary search")
+        pos = torch.as_tensor(pos_h).to(dev)
     if pos.numel() != panel.n_snps:
         raise _lib.LdxError("positions must have one entry per SNP")
-    if pos.numel() > 1 and bool((pos[1:] < pos[:-1]).any().item()):
-        raise _lib.LdxError("positions must ascend (VCF order): the window search is a binary search")
     if queries is None:
         q = torch.arange(panel.n_snps, dtype=torch.int32, device=dev)
     else:
         qn = np.sort(np.asarray(queries, dtype=np.int64))   # the kernel wants ascending rows
         if qn.size == 0:
             e = torch.empty(0, dtype=torch.int64, device=dev)
-            return AreaHits(e, e, torch.empty((0, 2), dtype=torch.float32, device=dev), 0)
+            return AreaHits(e, e, torch.empty((0, 2), dtype=torch.float32, device=dev), 0,
+                            torch.zeros(panel.n_snps + 1, dtype=torch.int32, device=dev))
         if qn[0] < 0 or qn[-1] >= panel.n_snps:
             raise _lib.LdxError("query row out of range")
         q = torch.as_tensor(qn.astype(np.int32)).to(dev)
     nq = int(q.numel())
     ws_bytes = lib.ldx_area_workspace_bytes(panel.n_snps, panel.n_hap, nq)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    fin_bytes = lib.ldx_area_finish_workspace_bytes(panel.n_snps)
+    fin = torch.empty(fin_bytes, dtype=torch.uint8, device=dev)
     n_hits = torch.zeros(1, dtype=torch.int64, device=dev)
-    cap = int(hit_capacity) if hit_capacity is not None else max(1 << 16, 64 * nq)
+    summary = torch.zeros(2, dtype=torch.int64, device=dev)
+    offsets = torch.empty(panel.n_snps + 1, dtype=torch.int32, device=dev)
+    cap = int(hit_capacity) if hit_capacity is not None else max(1 << 20, 16 * nq)   # slots (16 B each); an overflow re-runs with the exact count
     while True:
-        hits = torch.empty((cap, 4), dtype=torch.int32, device=dev)   # ldx_hit = {u32, u32, f32, f32}
+        raw = torch.empty((cap, 4), dtype=torch.int32, device=dev)      # ldx_hit = {u32, u32, f32, f32}
+        hits = torch.empty((cap, 4), dtype=torch.int32, device=dev)
         check(lib.ldx_area_dev(panel.alt.data_ptr(), panel.fa.data_ptr(), panel.fr.data_ptr(), panel.q.data_ptr(),
                                panel.n_snps, panel.n_hap, pos.data_ptr(), q.data_ptr(), nq, int(flank),
-                               MEASURES[measure], float(thres), hits.data_ptr(), cap, n_hits.data_ptr(),
+                               MEASURES[measure], float(thres), raw.data_ptr(), cap, n_hits.data_ptr(),
                                ws.data_ptr(), ws_bytes, _stream_ptr()), "ldx_area_dev")
-        reserved = int(n_hits.item())
+        check(lib.ldx_area_finish_dev(raw.data_ptr(), n_hits.data_ptr(), cap, panel.n_snps, hits.data_ptr(),
+                                      offsets.data_ptr(), summary.data_ptr(), fin.data_ptr(), fin_bytes,
+                                      _stream_ptr()), "ldx_area_finish_dev")
+        total, reserved = (int(x) for x in summary.tolist())             # the one host round trip
         if reserved <= cap:
             break
         cap = reserved + 4096            # the count is exact for a re-run: one retry suffices
-    hits = hits[:reserved]
-    valid = hits[:, 0] != -1             # UINT32_MAX marks an unused slot of a wave's batch
-    hits = hits[valid]
+    hits = hits[:total]
     qrow = hits[:, 0].to(torch.int64) & 0xFFFFFFFF
     orow = hits[:, 1].to(torch.int64) & 0xFFFFFFFF
-    order = torch.argsort(qrow * panel.n_snps + orow)
-    ld32 = hits[:, 2:4].contiguous().view(torch.float32)[order]
+    ld32 = hits[:, 2:4].contiguous().view(torch.float32)
+
     def count_pairs() -> int:
         # pairs evaluated = sum over queries of window population (bookkeeping, on device, only when asked for)
         qpos = pos[q.to(torch.int64)]
@@ -335,7 +360,11 @@ def ld_area(panel: PackedPanel, positions, queries: Optional[Sequence[int]] = No
         self_in = torch.clamp(qpos - flank, min=0) < qpos      # the query lies in its own window unless flank == 0
         return int((hi - lo).sum().item()) - int(self_in.sum().item())
 
-    return AreaHits(qrow[order], orow[order], ld32, count_pairs)
+    band = None
+    if get_area_path() != "popcount" and (get_area_path() != "auto" or (nq * 16 >= panel.n_snps and panel.n_snps >= 2)):
+        off = lib.ldx_area_band_passes_offset(panel.n_snps)
+        band = lambda: int(ws[off:off + 4].view(torch.int32).item())    # noqa: E731
+    return AreaHits(qrow, orow, ld32, count_pairs, offsets, band)
 
 
 # --------------------------------------------------------------------------- instrumentation

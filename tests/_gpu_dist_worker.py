@@ -77,6 +77,22 @@ def main():
         n_own = torch.tensor([len(own)], dtype=torch.int64)
         dist.all_reduce(n_own)
         assert int(n_own) == len(want)
+    # the WORK of the matrix-pipe band splits with the query ranges: a rank evaluates the passes its own queries can be
+    # part of (its share of the band + a halo of one window), not the whole band
+    n_snps, n_hap = 20000, 1008
+    whole = PackedPanel.from_codes(synth.synth_codes_device(n_snps, n_hap, seed=9, device=dev))
+    pos = synth.synth_positions(n_snps, step=500)
+    want = ld_area(whole, pos, None, 250000, "r_square", 0.8)
+    b, e = ldist.query_partition(pos, None, 250000, world)[rank]
+    mine = ld_area(whole, pos, list(range(b, e)), 250000, "r_square", 0.8)
+    assert mine.band_passes is not None and want.band_passes is not None
+    assert mine.band_passes <= 0.56 * want.band_passes, (mine.band_passes, want.band_passes)
+    tot = torch.tensor([mine.band_passes], dtype=torch.int64)
+    dist.all_reduce(tot)
+    assert want.band_passes <= int(tot) <= 1.12 * want.band_passes, (int(tot), want.band_passes)
+    got = ldist.ld_area_sharded(whole, pos, None, 250000, "r_square", 0.8)
+    assert torch.equal(got.query, want.query) and torch.equal(got.oppos, want.oppos)
+    assert torch.equal(got.ld32.view(torch.int32), want.ld32.view(torch.int32))
     torch.cuda.synchronize()
     dist.barrier()
     if rank == 0:

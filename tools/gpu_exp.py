@@ -71,7 +71,7 @@ def main():
         torch.cuda.synchronize()
         first = time.perf_counter() - t0
         t0 = time.perf_counter()
-        hits = ld_area(p, pos, None, 500000, "r_square", 0.8, hit_capacity=len(hits) + 600000)
+        hits = ld_area(p, pos, None, 500000, "r_square", 0.8)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         out.update(first_call_s=first, s=dt, ordered_pairs=hits.n_pairs, hits=len(hits),
