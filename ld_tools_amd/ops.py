@@ -289,7 +289,8 @@ class AreaHits:
 
 
 def ld_area(panel: PackedPanel, positions, queries: Optional[Sequence[int]] = None, flank: int = 100000,
-            measure: str = "r_square", thres: float = 0.8, hit_capacity: Optional[int] = None) -> AreaHits:
+            measure: str = "r_square", thres: float = 0.8, hit_capacity: Optional[int] = None,
+            check_positions: bool = True) -> AreaHits:
     """Windowed scan of ld_area.py:152-276 over the panel.
 
     positions: ascending 1-based coordinates of the panel's SNPs (VCF order).  queries: panel
@@ -304,7 +305,9 @@ def ld_area(panel: PackedPanel, positions, queries: Optional[Sequence[int]] = No
     dev = panel.device
     if isinstance(positions, torch.Tensor):
         pos = positions.to(dev, dtype=torch.int64).contiguous()
-        if pos.numel() > 1 and bool((pos[1:] < pos[:-1]).any().item()):
+        # a device tensor is checked on the device (one more host round trip); callers that scan one chromosome many
+        # times pass check_positions=False after the first call
+        if check_positions and pos.numel() > 1 and bool((pos[1:] < pos[:-1]).any().item()):
             raise _lib.LdxError("positions must ascend (VCF order): the window search is a binary search")
     else:
         pos_h = np.ascontiguousarray(np.asarray(positions, dtype=np.int64))
