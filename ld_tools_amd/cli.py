@@ -27,21 +27,21 @@ __version__ = "V11.2-ldx"
 def _common(argparser, with_src=True):
     if with_src:
         argparser.add_argument("-S", "--src-dir-path", metavar="str", dest="src_dir_path", type=str,
-                               help="Path to folder with source tables")
+                               help="Folder that holds the input tables (one job per table)")
     argparser.add_argument("-D", "--intgen-dir-path", metavar="str", dest="intgen_dir_path", type=str,
-                           help="Path to folder for 1000G data")
+                           help="Folder with the prepared 1000 Genomes files (per-chromosome VCFs, conversion.db)")
     if with_src:
         argparser.add_argument("-t", "--trg-top-dir-path", metavar="[None]", dest="trg_top_dir_path", type=str,
-                               help="Path to target folder (default: path to source folder)")
+                               help="Where result folders are created (if omitted: next to the input tables)")
         argparser.add_argument("-m", "--meta-lines-quan", metavar="[0]", default=0, dest="meta_lines_quan", type=int,
-                               help="Number of meta-information lines (including line with column names)")
+                               help="How many leading lines of each table to skip (headers, comments)")
     argparser.add_argument("-f", "--skip-intgen-data-ver", dest="skip_intgen_data_ver", action="store_true",
-                           help="Do not check 1000G data completeness (start main calculations immediately)")
+                           help="Trust the 1000 Genomes folder as it is and go straight to the LD computation")
     argparser.add_argument("-g", "--gend-names", metavar="[both]", choices=["male", "female", "both"], default="both",
                            dest="gend_names", type=str,
-                           help="{male, female, both} Belonging of 1000G samples to genders")
+                           help="{male, female, both} Which samples to use, by gender")
     argparser.add_argument("-e", "--pop-names", metavar="[all]", default="all", dest="pop_names", type=str,
-                           help="Belonging of 1000G samples to populations (separated by commas without space)")
+                           help="Which samples to use, by population / super-population codes: a comma-separated list, no blanks")
 
 
 def triangle_parser():
@@ -108,7 +108,23 @@ def _convdb(args):
     return intgen_dir_path, db
 
 
+# How the shells open a chromosome's VCF.  Default: pysam.VariantFile on ``{chrom}.vcf.gz`` (ld_triangle.py:128-129).
+# Another reader -- anything whose records offer ``id, pos, ref, alts, info, samples[name]['GT']`` and whose ``fetch``
+# follows pysam's overlap rule -- can be plugged in: set VCF_OPENER_FACTORY to a callable(intgen_dir_path) -> opener(chrom),
+# or name one in the environment as LDX_VCF_OPENER="module:function" (the tests run the shells end to end that way; pysam
+# is not part of this image).
+VCF_OPENER_FACTORY = None
+
+
 def _vcf_opener(intgen_dir_path):
+    factory = VCF_OPENER_FACTORY
+    spec = os.environ.get("LDX_VCF_OPENER")
+    if factory is None and spec:
+        import importlib
+        mod, _, fn = spec.partition(":")
+        factory = getattr(importlib.import_module(mod), fn)
+    if factory is not None:
+        return factory(intgen_dir_path)
     try:
         from pysam import VariantFile
     except ImportError as e:

@@ -19,13 +19,18 @@ _RS = re.compile(r"rs\d+$")
 
 
 def build_ucsc_header(header_key, header_val) -> str:
-    """One ``key=value`` element of the '##' header line (ld_area.py:3-14): strings quoted, tuples as a
-    comma-separated list of quoted elements, anything else through str()."""
-    if type(header_val).__name__ == "str":
-        header_val = f'"{header_val}"'
-    elif type(header_val).__name__ == "tuple":
-        header_val = ",".join([f'"{element}"' for element in header_val])
-    return f"{header_key}={header_val}"
+    """One ``key=value`` element of the '##' header line (format of ld_area.py:3-14): a string value goes in double
+    quotes, a tuple becomes its elements, each in double quotes, joined by commas; any other value is printed as is."""
+    def quoted(text):
+        return '"' + str(text) + '"'
+
+    if isinstance(header_val, tuple):
+        shown = ",".join(quoted(item) for item in header_val)
+    elif isinstance(header_val, str):
+        shown = quoted(header_val)
+    else:
+        shown = str(header_val)
+    return header_key + "=" + shown
 
 
 @dataclass
@@ -41,6 +46,23 @@ def _ann(rec) -> list:
     return [rec.pos, rec.id, rec.ref, ",".join(rec.alts), ",".join(rec.info["VT"])]
 
 
+def _clusters(queries, flank_size: int):
+    """Group the query records whose fetch windows [max(0, pos - flank), pos + flank] overlap or touch: every group is
+    read, packed and scanned on its own, so a handful of rsIDs spread over a chromosome costs a handful of windows, not the
+    span between the outermost two (the reference reads one window per query, ld_area.py:174-217).  Returns
+    [(lo, hi, [indices into ``queries``])] in ascending order of lo."""
+    order = sorted(range(len(queries)), key=lambda k: queries[k].pos)
+    groups = []
+    for k in order:
+        lo, hi = max(0, queries[k].pos - flank_size), queries[k].pos + flank_size
+        if groups and lo <= groups[-1][1]:
+            groups[-1][1] = max(groups[-1][1], hi)
+            groups[-1][2].append(k)
+        else:
+            groups.append([lo, hi, [k]])
+    return [(g[0], g[1], g[2]) for g in groups]
+
+
 def area_scan(vcf, chrom, chrom_rows: Sequence[Sequence], sample_names: Sequence[str], flank_size: int = 100000,
               ld_thres_measure: str = "r_square", ld_low_thres: float = 0.8) -> List[AreaQueryResult]:
     """The window loop of ld_area.py:152-276 for one chromosome, in the order of ``chrom_rows``.
@@ -49,8 +71,8 @@ def area_scan(vcf, chrom, chrom_rows: Sequence[Sequence], sample_names: Sequence
     record that overlaps that 0-based half-open interval (start = pos - 1, stop = start + len(ref)); opposing
     records with the query's id, an id that is not ``rs<digits>`` or a MULTI_ALLELIC flag are skipped
     (ld_area.py:222-225); var_1 = query, var_2 = opposing; a hit needs rounded measure >= threshold
-    (ld_area.py:248); hits come in VCF order.  Batched: the region covering all windows is read once, packed
-    once, and one windowed kernel launch evaluates every (query, opposing) pair."""
+    (ld_area.py:248); hits come in VCF order.  Batched per cluster of overlapping windows: the cluster's region is
+    read once, packed once, and one windowed kernel launch evaluates every (query, opposing) pair in it."""
     queries = []
     for pos, rs_id in chrom_rows:
         rec = find_record(vcf, chrom, int(pos), rs_id)
@@ -59,44 +81,44 @@ def area_scan(vcf, chrom, chrom_rows: Sequence[Sequence], sample_names: Sequence
         queries.append(rec)
     if not queries:
         return []
-    lo = max(0, min(q.pos for q in queries) - flank_size)
-    hi = max(q.pos for q in queries) + flank_size
-    region = list(vcf.fetch(chrom, lo, hi))                          # VCF order
     key = lambda r: (r.pos, r.id, r.ref, tuple(r.alts))              # noqa: E731  identity of a record
-    index = {}
-    for k, r in enumerate(region):
-        index.setdefault(key(r), k)
-    q_rows = [index[key(q)] for q in queries]                         # every query lies in the region by construction
-    genotypes = [sample_genotypes(r, sample_names) for r in region]
-    panel = PackedPanel.from_codes(codes_matrix(genotypes))
-    positions = np.array([r.pos for r in region], dtype=np.int64)
-    stops = np.array([r.pos - 1 + len(r.ref) for r in region], dtype=np.int64)
-    eligible = np.array([_RS.match(r.id or "") is not None and "MULTI_ALLELIC" not in r.info for r in region])
-    # the kernel's window is positional (low < pos_o <= high); long REF alleles that start before the window but
-    # overlap it are reached by widening the lower flank, and the exact overlap rule is applied to the hits below
-    extra = int((stops - (positions - 1)).max()) - 1
-    uniq_q = sorted(set(q_rows))
-    hits = ld_area(panel, positions, uniq_q, flank=flank_size + extra, measure=ld_thres_measure, thres=ld_low_thres)
-    hq = hits.query.cpu().numpy()
-    ho = hits.oppos.cpu().numpy()
-    hv = hits.python_values(panel)                                   # [(r2, D')] as the reference's Python values
-    alt_freq = panel.alt_freq4().cpu().numpy()
-    by_query = {}
-    for qrow, orow, (r2, dp) in zip(hq.tolist(), ho.tolist(), hv):
-        by_query.setdefault(qrow, []).append((orow, r2, dp))
-    results = []
-    for q, qrow in zip(queries, q_rows):
-        low = max(0, q.pos - flank_size)
-        high = q.pos + flank_size
-        res = AreaQueryResult(q.id, _ann(q) + [float(alt_freq[qrow])] + ["quer"] * 3)    # ld_area.py:188-196
-        for orow, r2, dp in by_query.get(qrow, ()):                 # ascending panel row = VCF order
-            o = region[orow]
-            if not eligible[orow] or o.id == q.id:
-                continue
-            if not (positions[orow] - 1 < high and stops[orow] > low):                # pysam overlap with [low, high)
-                continue
-            res.hits.append(_ann(o) + [float(alt_freq[orow]), r2, dp, o.pos - q.pos])
-        results.append(res)
+    results: List[Optional[AreaQueryResult]] = [None] * len(queries)
+    for lo, hi, members in _clusters(queries, flank_size):
+        region = list(vcf.fetch(chrom, lo, hi))                          # VCF order
+        index = {}
+        for k, r in enumerate(region):
+            index.setdefault(key(r), k)
+        q_rows = {m: index[key(queries[m])] for m in members}           # every query lies in its cluster's region
+        genotypes = [sample_genotypes(r, sample_names) for r in region]
+        panel = PackedPanel.from_codes(codes_matrix(genotypes))
+        positions = np.array([r.pos for r in region], dtype=np.int64)
+        stops = np.array([r.pos - 1 + len(r.ref) for r in region], dtype=np.int64)
+        eligible = np.array([_RS.match(r.id or "") is not None and "MULTI_ALLELIC" not in r.info for r in region])
+        # the kernel's window is positional (low < pos_o <= high); long REF alleles that start before the window but
+        # overlap it are reached by widening the lower flank, and the exact overlap rule is applied to the hits below
+        extra = int((stops - (positions - 1)).max()) - 1
+        uniq_q = sorted(set(q_rows.values()))
+        hits = ld_area(panel, positions, uniq_q, flank=flank_size + extra, measure=ld_thres_measure, thres=ld_low_thres)
+        hq = hits.query.cpu().numpy()
+        ho = hits.oppos.cpu().numpy()
+        hv = hits.python_values(panel)                                   # [(r2, D')] as the reference's Python values
+        alt_freq = panel.alt_freq4().cpu().numpy()
+        by_query = {}
+        for qrow, orow, (r2, dp) in zip(hq.tolist(), ho.tolist(), hv):
+            by_query.setdefault(qrow, []).append((orow, r2, dp))
+        for m in members:
+            q, qrow = queries[m], q_rows[m]
+            low = max(0, q.pos - flank_size)
+            high = q.pos + flank_size
+            res = AreaQueryResult(q.id, _ann(q) + [float(alt_freq[qrow])] + ["quer"] * 3)    # ld_area.py:188-196
+            for orow, r2, dp in by_query.get(qrow, ()):                 # ascending panel row = VCF order
+                o = region[orow]
+                if not eligible[orow] or o.id == q.id:
+                    continue
+                if not (positions[orow] - 1 < high and stops[orow] > low):                # pysam overlap with [low, high)
+                    continue
+                res.hits.append(_ann(o) + [float(alt_freq[orow]), r2, dp, o.pos - q.pos])
+            results[m] = res
     return results
 
 

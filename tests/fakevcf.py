@@ -76,3 +76,9 @@ def make_chromosome(chrom="6", n_variants=48, n_samples=40, seed=11, first_pos=1
     for r in records:
         r.samples.pop(names[7], None)
     return FakeVcf(records), names
+
+
+def opener_factory(intgen_dir_path):
+    """For ld_tools_amd.cli (LDX_VCF_OPENER="fakevcf:opener_factory"): every chromosome opens the synthetic one."""
+    vcf, _ = make_chromosome()
+    return lambda chrom: vcf

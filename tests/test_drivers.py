@@ -232,3 +232,144 @@ def test_ld_lite_table(chrom6):
                                       tablefmt="fancy_grid", disable_numparse=True), f"\n\n\n{id1}", f"\n\n\n{id2}"],
                     tablefmt="fancy_grid")                    # ld_lite.py:148-159
     assert ld_lite_table(vcf, "6", id1, p1, id2, p2, names) == want
+
+
+# ------------------------------------------------------------------------------------------ the three shells, end to end
+def _intgen_folder(tmp_path, vcf, names, genders):
+    """A prepared '1000 Genomes folder' as the shells expect it: conversion.db with the ``samples`` and ``variants`` tables
+    (backend/prep_intgen_data.py builds them in the reference; same-rsID repeats are dropped there too)."""
+    d = tmp_path / "intgen"
+    d.mkdir()
+    with sqlite3.connect(d / "conversion.db") as conn:
+        conn.execute("CREATE TABLE samples (sample TEXT, pop TEXT, super_pop TEXT, gender TEXT)")
+        conn.executemany("INSERT INTO samples VALUES (?, ?, ?, ?)",
+                         [(n, "GBR" if k % 2 else "PEL", "EUR" if k % 2 else "AMR", genders[k % len(genders)])
+                          for k, n in enumerate(names)])
+        conn.execute("CREATE TABLE variants (CHROM TEXT, POS INTEGER, ID TEXT)")
+        seen = set()
+        for r in vcf.records:
+            if r.id.startswith("rs") and ";" not in r.id and r.id not in seen:
+                seen.add(r.id)
+                conn.execute("INSERT INTO variants VALUES (?, ?, ?)", (r.chrom, r.pos, r.id))
+    return d
+
+
+def _run_shell(script, argv, cwd):
+    env = dict(os.environ, LDX_VCF_OPENER="fakevcf:opener_factory",
+               PYTHONPATH=os.pathsep.join([str(ROOT / "tests"), str(ROOT), os.environ.get("PYTHONPATH", "")]))
+    r = __import__("subprocess").run([sys.executable, str(ROOT / script)] + argv, capture_output=True, text=True, timeout=600,
+                                     env=env, cwd=str(cwd))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    return r.stdout
+
+
+@pytest.mark.gpu
+def test_ld_triangle_shell_end_to_end(chrom6, tmp_path):
+    """`python3 ld_triangle.py -S ... -D ... -f -o table ...` with the reference's flags writes the reference's folder tree
+    and table text (ld_triangle.py:364-411, 52-360): one run per (measure, threshold) of the golden set."""
+    vcf, names, tri_rows, _ = chrom6
+    intgen = _intgen_folder(tmp_path, vcf, names, ["male", "female"])
+    src = tmp_path / "src"
+    src.mkdir()
+    (src / "study.tsv").write_text("col_a\tcol_b\n" + "".join(f"x\t{rs}\tgene\n" for _, rs in tri_rows[::-1]))
+    for key, text in GOLD["triangle"].items():
+        measure, thres = key.split("|")
+        trg = tmp_path / f"out_{measure}_{thres}"
+        trg.mkdir()
+        argv = ["-S", str(src), "-D", str(intgen), "-t", str(trg), "-m", "1", "-f", "-e", "eur,amr", "-l", measure, "-o", "table",
+                "-p", "8"]
+        if thres != "None":
+            argv += ["-z", thres]
+        out = _run_shell("ld_triangle.py", argv, tmp_path)
+        assert "parallel computation time" in out
+        tree = sorted(str(p.relative_to(trg)) for p in trg.rglob("*") if p.is_file())
+        assert tree == [f"study_LD_matr/study_chr6_{measure[0]}.tsv"]
+        assert (trg / tree[0]).read_text() == text
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ftype", ["tsv", "json", "rsids"])
+def test_ld_area_shell_end_to_end(chrom6, tmp_path, ftype):
+    """`python3 ld_area.py -S ... -D ... -f -w ... -z ... -o ...`: folder tree {table}_in_LD/{chrom}/ and every file's bytes
+    (ld_area.py:296-342, 62-292)."""
+    vcf, names, _, queries = chrom6
+    intgen = _intgen_folder(tmp_path, vcf, names, ["female"])          # the golden header says gends="female"
+    src = tmp_path / "src"
+    src.mkdir()
+    (src / "gwas_hits.txt").write_text("".join(f"{rs} p=1e-9\n" for _, rs in queries))
+    for k, (measure, thres, flank) in enumerate(AREA_CASES):
+        want = GOLD["area"][f"{ftype}|{measure}|{thres}|{flank}"]
+        trg = tmp_path / f"out{k}"
+        trg.mkdir()
+        _run_shell("ld_area.py", ["-S", str(src), "-D", str(intgen), "-t", str(trg), "-f", "-g", "female", "-w", str(flank),
+                                  "-l", measure, "-z", str(thres), "-o", ftype], tmp_path)
+        got = {str(p.relative_to(trg)): p.read_text() for p in trg.rglob("*") if p.is_file()}
+        assert sorted(got) == sorted(f"gwas_hits_in_LD/6/{name}" for name in want)
+        for name, text in want.items():
+            assert got[f"gwas_hits_in_LD/6/{name}"] == text, name
+
+
+@pytest.mark.gpu
+def test_ld_lite_shell_end_to_end(chrom6, tmp_path):
+    """`python3 ld_lite.py rsA rsB -D ... -f` prints the reference's nested table (ld_lite.py:49-159); its error types for
+    a non-rs id, an unknown id and two chromosomes."""
+    pytest.importorskip("tabulate")
+    from tabulate import tabulate
+    vcf, names, tri_rows, _ = chrom6
+    intgen = _intgen_folder(tmp_path, vcf, names, ["male", "female"])
+    (p1, id1), (p2, id2) = tri_rows[2], tri_rows[9]
+    r1 = next(r for r in vcf.records if r.id == id1)
+    r2 = next(r for r in vcf.records if r.id == id2)
+    vals = orc.calc_ld_lists(ref_loops._genotypes(r1, names), ref_loops._genotypes(r2, names))
+    want = tabulate([["chrom", "6", "6"], ["hg38_pos", p1, p2], ["alleles", "A/G", "A/G"], ["type", "SNP", "SNP"],
+                     ["alt_freq", vals["var_1_alt_freq"], vals["var_2_alt_freq"]]],
+                    headers=[tabulate([["r2", vals["r_square"]], ["D'", vals["d_prime"]], ["abs_dist", abs(p1 - p2)]],
+                                      tablefmt="fancy_grid", disable_numparse=True), f"\n\n\n{id1}", f"\n\n\n{id2}"],
+                    tablefmt="fancy_grid")
+    out = _run_shell("ld_lite.py", [id1, id2, "-D", str(intgen), "-f"], tmp_path)
+    assert out.rstrip("\n") == want
+    from ld_tools_amd import cli
+    from ld_tools_amd.drivers import DifChrsError, NotInIntgenConvDbError, NotRsIdError
+    cli.VCF_OPENER_FACTORY = fakevcf.opener_factory
+    try:
+        with pytest.raises(NotRsIdError):
+            cli.ld_lite_main(["esv1", id2, "-D", str(intgen), "-f"])
+        with pytest.raises(NotInIntgenConvDbError):
+            cli.ld_lite_main([id1, "rs424242", "-D", str(intgen), "-f"])
+        with sqlite3.connect(intgen / "conversion.db") as conn:
+            conn.execute("INSERT INTO variants VALUES ('7', 5, 'rs777')")
+        with pytest.raises(DifChrsError):
+            cli.ld_lite_main([id1, "rs777", "-D", str(intgen), "-f"])
+    finally:
+        cli.VCF_OPENER_FACTORY = None
+
+
+@pytest.mark.gpu
+def test_area_scan_reads_one_window_per_cluster(chrom6):
+    """Queries far apart are fetched, packed and scanned per cluster of overlapping windows, not over the span between the
+    outermost two; the results equal the single-region scan."""
+    from ld_tools_amd.drivers import area_scan
+    from ld_tools_amd.drivers.area import _clusters
+    vcf, names, _, queries = chrom6
+    wide = area_scan(vcf, "6", queries, names, 10 ** 6, "r_square", 0.3)      # one cluster: the whole chromosome
+    spans = []
+    real_fetch = vcf.fetch
+    def spy(chrom, start, end):
+        if end - start > 2:                                                   # window reads, not the per-query lookups
+            spans.append((start, end))
+        return real_fetch(chrom, start, end)
+    vcf.fetch = spy
+    try:
+        narrow = area_scan(vcf, "6", queries, names, 150, "r_square", 0.3)
+    finally:
+        del vcf.fetch
+    recs = [next(r for r in vcf.records if r.id == rs and r.pos == pos) for pos, rs in queries]
+    assert len(spans) == len(_clusters(recs, 150)) > 3
+    assert max(e - s for s, e in spans) < 3000 < vcf.records[-1].pos - vcf.records[0].pos
+    assert sum(len(r.hits) for r in wide) > sum(len(r.hits) for r in narrow) > 0
+    # the narrow scan equals the reference's loop (restated, with the oracle's calc_ld) query by query
+    ref = ref_loops.area_files(vcf, "6", queries, names, 150, "r_square", 0.3, "rsids", ("ALL",), ("male",), orc.calc_ld_lists)
+    got_ids = {f"{r.query_id}_chr6_r_0.3.txt": [r.query_id] + [h[1] for h in r.hits] for r in narrow if r.hits}
+    assert sorted(got_ids) == sorted(ref)
+    for name, text in ref.items():
+        assert text.splitlines()[2:] == got_ids[name], name
