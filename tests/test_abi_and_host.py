@@ -93,6 +93,34 @@ def test_encode_codes_matches_list_count_semantics():
     assert encode_codes(np.array([0, 1, 2, 3, 1], dtype=np.int64)).tolist() == [0, 1, 2, 2, 1]
     assert encode_codes(np.array([[0.0, 1.0], [np.nan, 2.0]])).tolist() == [[0, 1], [2, 2]]
     assert encode_codes((1, 0, 1)).tolist() == [1, 0, 1]
+    # every list shape takes its own path (bytes() for small ints, numeric arrays, objects) and all follow list.count
+    for seq in ([1, 0] * 50, ["1", 1, 0], [300, 1, 0, -1], [2.0, 1.0, 0.5], (1, 0, "x"), [True, 1, False, 255, 256]):
+        assert encode_codes(seq).tolist() == [1 if v == 1 else (0 if v == 0 else 2) for v in seq], seq
+    assert encode_codes([[1, None], [0, 1]]).tolist() == [[1, 2], [0, 1]]
+    assert encode_codes([]).tolist() == [] and encode_codes([]).dtype == np.int8
+
+
+def test_f32_cell_value_from_k_is_the_nearest_float32():
+    """ldx_common.h f32_k_to_value: q = k * fl(1e-4); r = fma(-q, 1e4, k); q' = fma(r, fl(1e-4), q) must be the float32
+    nearest to k / 10^4 for every k the 4-byte cell can hold.  Emulated with exact rationals (one rounding per operation)."""
+    from fractions import Fraction
+
+    def rn32(x: Fraction) -> Fraction:          # round an exact rational to float32 (the values here are far from overflow)
+        if x == 0:
+            return Fraction(0)
+        f = np.float32(float(x))                 # float(x) is correctly rounded to double; a second rounding to float32 can
+        lo, hi = np.nextafter(f, np.float32(-np.inf)), np.nextafter(f, np.float32(np.inf))   # differ from direct rounding
+        best = min((lo, f, hi), key=lambda c: (abs(Fraction(float(c)) - x), int(np.float32(c).view(np.uint32)) & 1))
+        return Fraction(float(best))
+
+    c4 = Fraction(float(np.float32(1e-4)))
+    for k in list(range(0, 12000)) + list(range(12000, 32768, 7)) + [32766, 32767]:
+        kk = Fraction(k)
+        q = rn32(kk * c4)
+        r = rn32(-q * 10000 + kk)
+        got = rn32(r * c4 + q)
+        want = Fraction(float(np.float32(k / 10000.0)))     # k / 1e4 in double, then float32: the encoders' definition
+        assert got == want, k
 
 
 def test_unit_partition_covers_every_pair_once():

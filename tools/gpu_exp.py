@@ -7,6 +7,7 @@
     python tools/gpu_exp.py eur        # configs[4] shape on the popcount path: 50k x 1008
     python tools/gpu_exp.py pack       # pack kernel bandwidth
     python tools/gpu_exp.py small      # configs[0] and other driver-sized tables: codes on the host -> ld_two_dim on the host
+    python tools/gpu_exp.py calc       # the drop-in calc_ld pair by pair: microseconds per call
 """
 import json
 import sys
@@ -50,8 +51,8 @@ def main():
             codes = synth.synth_codes_host(n, 5008, seed=3)
             def whole():                                          # drivers/triangle.py: triangle_matrix without the VCF reads
                 p = PackedPanel.from_codes(codes)                 # H2D + pack
-                dense = ld_triangle(p).dense("r_square", None).cpu().numpy()
-                flat = k_to_python(dense)
+                dense, fixes = ld_triangle(p).dense_values("r_square", None)
+                flat = k_to_python(dense, fixes)
                 return [flat[r * n:(r + 1) * n] for r in range(n)]   # the reference's ld_two_dim
             whole()
             t0 = time.perf_counter()
@@ -98,6 +99,20 @@ def main():
         p = PackedPanel.empty(n, h)
         ms = timed(lambda: p.pack_from(codes), reps=5)
         out.update(ms=ms, gbps_in=n * h / (ms * 1e-3) / 1e9)
+    elif what == "calc":
+        # the drop-in calc_ld, pair by pair (INTEGRATION.md level 0): microseconds per call for lists and for int8 arrays
+        import numpy as np
+
+        from ld_tools_amd.backend.calc_ld import calc_ld
+        codes = synth.synth_codes_host(2, 5008, seed=3)
+        g1, g2 = codes[0].tolist(), codes[1].tolist()
+        a1, a2 = codes[0].copy(), codes[1].copy()
+        for name, x, y in (("lists", g1, g2), ("int8_arrays", a1, a2)):
+            calc_ld(x, y)
+            t0 = time.perf_counter()
+            for _ in range(300):
+                calc_ld(x, y)
+            out[name + "_us_per_call"] = (time.perf_counter() - t0) / 300 * 1e6
     print(json.dumps(out), flush=True)
 
 
