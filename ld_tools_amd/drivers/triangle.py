@@ -41,7 +41,7 @@ def triangle_matrix(vcf, chrom, chrom_rows: Sequence[Sequence], sample_names: Se
         alleles.append(rec.ref + "/" + rec.alts[0] if rec is not None else "")
         types.append(rec.info["VT"][0] if rec is not None else "")
     panel = PackedPanel.from_codes(codes_matrix(genotypes))
-    res = ld_triangle(panel)
+    res = ld_triangle(panel, fmt="k16")                               # 4-byte cells: k and the int-0 mark, lossless
     n = len(rows)
     dense, fixes = res.dense_values(ld_measure, ld_low_thres)        # -0.0 = the template's / a computed int 0
     flat = k_to_python(dense, fixes)
