@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(1024) calc_ld_pair_kernel(const int8_t *__rest
         for (int off = 32; off > 0; off >>= 1) c[k] += __shfl_xor(c[k], off);
         if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6][k] = c[k];
     }
-    __syncthreads();
+    block_sync();
     if (threadIdx.x == 0) {
         uint32_t t[5] = {0, 0, 0, 0, 0};
         for (uint32_t w = 0; w < blockDim.x / 64u; ++w)

@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(1024) area_plan_kernel(const int64_t *__restri
     __shared__ uint64_t carry;
     __shared__ uint32_t wsum[16];
     if (threadIdx.x == 0) { carry = 0; w.unit_base[0] = 0; }
-    __syncthreads();
+    block_sync();
     for (uint32_t t0 = 0; t0 < T; t0 += 1024u) {
         const uint32_t t = t0 + threadIdx.x;
         uint32_t cnt = 0;
@@ -114,14 +114,14 @@ __global__ void __launch_bounds__(1024) area_plan_kernel(const int64_t *__restri
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(x, off); if (lane >= (uint32_t)off) x += y; }
         if (lane == 63) wsum[wv] = x;
-        __syncthreads();
+        block_sync();
         uint32_t pre = 0;
         for (uint32_t k = 0; k < wv; ++k) pre += wsum[k];
         const uint64_t incl = carry + pre + x;
         if (t < T) w.unit_base[t + 1] = incl;
-        __syncthreads();
+        block_sync();
         if (threadIdx.x == 1023) carry = incl;
-        __syncthreads();
+        block_sync();
     }
 }
 
@@ -155,14 +155,14 @@ area_scan_kernel(const uint4 *__restrict__ alt, const uint4 *__restrict__ qalt, 
             if (te <= u) { ++t; continue; }   // empty tile
             const uint64_t seg_end = b1 < te ? b1 : te;
             const uint32_t seg_len = (uint32_t)(seg_end - u);
-            __syncthreads();
+            block_sync();
             stage_tile(jt, alt + (size_t)t * nchunks * kSlab, nchunks * kSlab);
             const uint32_t o0 = t * kSlab + lane, o1 = o0 + 64u;
             const bool ov[2] = {o0 < n_snps, o1 < n_snps};
             const double fa2[2] = {fa[o0], fa[o1]};
             const double fr2[2] = {fr[o0], fr[o1]};
             const int64_t po[2] = {ov[0] ? pos[o0] : 0, ov[1] ? pos[o1] : 0};
-            __syncthreads();
+            block_sync();
             const uint32_t gfirst = g_begin[t];
 
             for (uint32_t k = wave; k < seg_len; k += kWaves) {
@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(1024) area_offsets_kernel(const uint32_t *__re
     __shared__ uint32_t carry;
     __shared__ uint32_t wsum[16];
     if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
+    block_sync();
     for (uint32_t k0 = 0; k0 < n_snps; k0 += 1024u) {
         const uint32_t k = k0 + threadIdx.x;
         const uint32_t c = k < n_snps ? counts[k] : 0u;
@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(1024) area_offsets_kernel(const uint32_t *__re
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(x, off); if (lane >= (uint32_t)off) x += y; }
         if (lane == 63) wsum[wv] = x;
-        __syncthreads();
+        block_sync();
         uint32_t pre = 0;
         for (uint32_t w = 0; w < wv; ++w) pre += wsum[w];
         const uint32_t incl = carry + pre + x;
@@ -262,9 +262,9 @@ __global__ void __launch_bounds__(1024) area_offsets_kernel(const uint32_t *__re
             offsets[k] = incl - c;
             cursor[k] = incl - c;
         }
-        __syncthreads();
+        block_sync();
         if (threadIdx.x == 1023) carry = incl;
-        __syncthreads();
+        block_sync();
     }
     if (threadIdx.x == 0) {
         offsets[n_snps] = carry;

@@ -17,6 +17,18 @@ constexpr uint32_t kGroupsPerSlab = kSlab / kGroup;   // 16
 
 void set_error(const char *fmt, ...);
 
+// Workgroup barrier that first drains THIS wave's LDS traffic.  hipcc (ROCm 7.2) lowers __syncthreads() to a fence of the
+// local address space + s_barrier, and for such a fence LLVM's gfx9 memory model emits NO s_waitcnt lgkmcnt(0): it takes
+// the LDS operations of all waves to execute in one total order.  On gfx950 with two workgroups per CU that did not
+// hold: a ds_write (the pass ticket) issued just before the barrier was, about once in 10^6 barriers, not yet visible
+// to a ds_read another wave issued right behind it -- that wave then redid an old pass and left its own undone
+// (tools/gpu_soak.py).  Every barrier in these sources goes through here.
+__device__ __forceinline__ void block_sync()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
 // Smallest integer k >= 0 with (double)k / 1e4 >= thres: "rounded value >= thres" (ld_area.py:248,
 // ld_triangle.py:224) becomes the exact integer test k >= thres_to_k(thres).
 double thres_to_k(double thres);

@@ -211,7 +211,7 @@ struct AreaArgs {
     F32Const f32;                  // the fp32 epilogue tier's constants (triangle launches use only this member)
 };
 constexpr uint32_t kHitBatch = 256;   // hit slots a wave reserves per atomic (as in ldx_area.hip)
-constexpr uint32_t kQueueCap = 128;   // fp32 tier: lane-steps a wave can park for the fp64 tier (drained 64 at a time)
+constexpr uint32_t kQueueCap = 128;   // fp32 tier: lane-steps a wave can park for the fp64 tier
 // dynamic LDS of the kernel: the two j-tile image buffers, the fp64 operand tables, tickets, and for the FP4 triangle
 // kernel the fp32 tables and the four queues
 constexpr size_t mfma_lds_bytes(uint32_t stat_rows, bool f32_tier)
@@ -314,9 +314,11 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                                             kMfmaWaves * kQueueCap) + wave * (kQueueCap * 8u);   // [kQueueCap][8] counts
     const F32Const fc32 = aa.f32;   // computed on the host (f32_const): kernel arguments live in scalar registers
     auto draw = [&]() { return atomicAdd(&sched[0], 1u); };
-    // this CU's K-loop token (triangle launches; the band kernel's epilogue is too short for an alternation to pay)
+    // this CU's K-loop token: OFF in product builds.  Tuning builds switch it on with LDX_ABLATE bit 4096 to make the
+    // stamps readable (K loop alone on the matrix pipe: 29.3k cycles per unit).  It buys nothing on the wall clock: the
+    // two waves of a SIMD are bound by their combined instruction issue.
     uint32_t *ktok = nullptr;
-    if (!kArea && !(ablate_arg & 4096)) {
+    if (!kArea && (ablate_arg & 4096)) {
         const uint32_t hw = __builtin_amdgcn_s_getreg(63492), xcc = __builtin_amdgcn_s_getreg(63508);   // HW_ID, XCC_ID
         ktok = sched + 2u + ((((xcc & 7u) * 8u + ((hw >> 13) & 7u)) * 2u + ((hw >> 12) & 1u)) * 16u + ((hw >> 8) & 15u));
     }
@@ -326,7 +328,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
     uint64_t hit_slot = 0, hit_slot_end = 0;   // area: this wave's unfilled part of its current batch of hit slots
     uint32_t t_prev = 0xFFFFFFFFu;
     for (;;) {   // block-uniform: every wave reaches every barrier
-        __syncthreads();   // the ticket is in LDS; every wave is past its previous epilogue (both B buffers free)
+        block_sync();   // the ticket is in LDS; every wave is past its previous epilogue (both B buffers free)
         const uint32_t ticket = tickets[parity];
         parity ^= 1u;
         if (ticket >= n_tickets) {   // block-uniform; the last workgroup out re-arms the counters
@@ -537,7 +539,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
             }
             if (ktok && tid == 0)   // one workgroup per CU in its K loop at a time (see g_sched)
                 while (atomicCAS(ktok, 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(4);
-            __syncthreads();
+            block_sync();
             LDX_STAMP(1);
             if (ablate & 32) __builtin_amdgcn_s_setprio(2);   // tuning: the K-loop wave outranks the epilogue wave instead
             v4i af0[MM], bf0[4], af1[MM], bf1[4];
@@ -793,8 +795,8 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
             // Per step each lane runs its 8 pairs through ld_multi_f32 and tests ONCE whether all of them are provably
             // rounded like the reference; if so it stores its 8 cells, if not it parks the step (id + 8 counts) in the
             // wave's LDS queue.  The queue is drained AFTER the sixteen steps -- the accumulators are dead by then, so the
-            // fp64 tier (ld_multi_fast2, and the op-for-op mirror behind it) has the registers it wants -- 64 entries at
-            // a time, one parked step per lane: the rare path runs at full lane occupancy.  A unit that parks more steps
+            // fp64 tier (ld_multi_fast2, and the op-for-op mirror behind it) has the registers it wants -- eight entries
+            // at a time, one parked PAIR per lane: the rare path runs at full lane occupancy.  A unit that parks more steps
             // than the queue holds is redone as a whole by the fp64 epilogue (returns false).
             auto epilogue_f32 = [&]() -> bool {
               if constexpr (kF32Tier && MM == 2) {
@@ -886,7 +888,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                         qn += np;
                     }
                 }
-                // ---- the parked steps: fp64 tier, one step (8 pairs) per lane ----
+                // ---- the parked steps: fp64 tier ----
                 LDX_COUNT(0, 1);
                 LDX_COUNT(1, qn);
                 if ((ablate & 2048) != 0) qn = 0;   // tuning: skip the drain (results wrong)
@@ -894,44 +896,36 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                     __builtin_amdgcn_s_waitcnt(0xC07F);   // this wave's queue writes have landed (lgkmcnt(0))
                     __builtin_amdgcn_wave_barrier();
                 }
-                for (uint32_t q0 = 0; q0 < qn; q0 += 64u) {   // wave-uniform
-                    if (q0 + lane < qn) {
-                        const uint32_t id = qid[q0 + lane];
+                // one PAIR per lane: eight lanes share a parked step (lane % 8 = 4 m + tt), so the usual handful of entries
+                // is one short batch at full occupancy instead of a 64-lane batch with a few busy lanes doing eight pairs each
+                // (lane-derived values recomputed from an opaque copy of the lane id, as above: hoisted out of the pass loop
+                // they would be spilled to scratch around the K loop)
+                uint32_t ld = ln;
+                asm volatile("" : "+v"(ld));
+                for (uint32_t q0 = 0; q0 < qn; q0 += 8u) {   // wave-uniform
+                    const uint32_t ent = q0 + (ld >> 3), pr = ld & 7u;
+                    if (ent < qn) {
+                        const uint32_t id = qid[ent];
                         const uint32_t e2 = id >> 8, l2 = id & 31u, h2 = (id >> 5) & 1u;
-                        const v4f *src = reinterpret_cast<const v4f *>(qcnt + (size_t)(q0 + lane) * 8u);
-                        const v4f c0 = src[0], c1 = src[1];
-                        const float cq[2][4] = {{c0.x, c0.y, c0.z, c0.w}, {c1.x, c1.y, c1.z, c1.w}};
-                        uint32_t ri2[2];
-                        FastRow frk[2];
-#pragma unroll
-                        for (int m = 0; m < 2; ++m) {
-                            ri2[m] = 32u * m + (e2 & 3u) + 8u * (e2 >> 2) + 4u * h2;
-                            const d2 *rs = reinterpret_cast<const d2 *>(rstat + ri2[m] * kStat);
-                            const d2 r01 = rs[0], r23 = rs[1];
-                            frk[m] = FastRow{r01.x, r01.y, r23.x, r23.y};
-                        }
-#pragma unroll
-                        for (int tt = 0; tt < 4; ++tt) {
-                            const uint32_t cl = 32u * tt + l2;
-                            const d2 *cs = reinterpret_cast<const d2 *>(cstat + cl * kStat);
-                            const d2 c01 = cs[0], c23 = cs[1];
-                            const FastCol fcx[2] = {FastCol{c01.x, c01.y, c23.x, c23.y}, FastCol{c01.x, c01.y, c23.x, c23.y}};
-                            const float a2[2] = {cq[0][tt], cq[1][tt]};
-                            Cell r2[2];
-                            bool s2[2];
-                            ld_multi_fast2<2, true, Cell>(a2, fk, frk, fcx, r2, s2);
-#pragma unroll
-                            for (int m = 0; m < 2; ++m) {
-                                if (s2[m]) {   // near a rounding tie, Dn == 0: the exact mirror
-                                    const uint32_t i = row0 + ri2[m], j = t * kSlab + cl;
-                                    r2[m] = encode_cell<Cell>(ld_pair_mirror((double)a2[m] / n, fa[i], fr[i], q[i], fa[j], fr[j]));
+                        const float a2[1] = {qcnt[(size_t)ent * 8u + pr]};
+                        const uint32_t ri2 = 32u * (pr >> 2) + (e2 & 3u) + 8u * (e2 >> 2) + 4u * h2, cl = 32u * (pr & 3u) + l2;
+                        const d2 *rs = reinterpret_cast<const d2 *>(rstat + ri2 * kStat);
+                        const d2 r01 = rs[0], r23 = rs[1];
+                        const FastRow frk[1] = {FastRow{r01.x, r01.y, r23.x, r23.y}};
+                        const d2 *cs = reinterpret_cast<const d2 *>(cstat + cl * kStat);
+                        const d2 c01 = cs[0], c23 = cs[1];
+                        const FastCol fcx[1] = {FastCol{c01.x, c01.y, c23.x, c23.y}};
+                        Cell r2[1];
+                        bool s2[1];
+                        ld_multi_fast2<1, true, Cell>(a2, fk, frk, fcx, r2, s2);
+                        if (s2[0]) {   // near a rounding tie, Dn == 0: the exact mirror
+                            const uint32_t i = row0 + ri2, j = t * kSlab + cl;
+                            r2[0] = encode_cell<Cell>(ld_pair_mirror((double)a2[0] / n, fa[i], fr[i], q[i], fa[j], fr[j]));
 #ifdef LDX_TUNING
-                                    atomicAdd(&g_dbg[3], 1ull);
+                            atomicAdd(&g_dbg[3], 1ull);
 #endif
-                                }
-                                ubase[(size_t)(ri2[m] / kGroup) * LDX_UNIT_PAIRS + (ri2[m] % kGroup) * kSlab + cl] = r2[m];
-                            }
                         }
+                        ubase[(size_t)(ri2 / kGroup) * LDX_UNIT_PAIRS + (ri2 % kGroup) * kSlab + cl] = r2[0];
                     }
                 }
                 return true;
@@ -1284,7 +1278,7 @@ __global__ void __launch_bounds__(1024) area_band_plan_kernel(const int64_t *__r
     __shared__ uint32_t carry;
     __shared__ uint32_t wsum[16];
     if (threadIdx.x == 0) { carry = 0; pass_base[0] = 0; }
-    __syncthreads();
+    block_sync();
     for (uint32_t t0 = 0; t0 < T; t0 += 1024u) {
         const uint32_t t = t0 + threadIdx.x;
         uint32_t cnt = 0;
@@ -1310,14 +1304,14 @@ __global__ void __launch_bounds__(1024) area_band_plan_kernel(const int64_t *__r
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(x, off); if (lane >= (uint32_t)off) x += y; }
         if (lane == 63) wsum[wv] = x;
-        __syncthreads();
+        block_sync();
         uint32_t pre = 0;
         for (uint32_t k = 0; k < wv; ++k) pre += wsum[k];
         const uint32_t incl = carry + pre + x;
         if (t < T) pass_base[t + 1u] = incl;
-        __syncthreads();
+        block_sync();
         if (threadIdx.x == 1023) carry = incl;
-        __syncthreads();
+        block_sync();
     }
 }
 

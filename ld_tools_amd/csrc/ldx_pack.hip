@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(256) pack_codes_kernel(const int8_t *__restric
             if (rcnt && cr) atomicAdd(&rcnt[row], cr);
         }
     }
-    __syncthreads();
+    block_sync();
     const uint32_t chunk = t >> 7, rin = t & 127u;
     if (c0 + chunk < nchunks) {
         const size_t idx = ((size_t)slab * nchunks + c0 + chunk) * kSlab + rin;

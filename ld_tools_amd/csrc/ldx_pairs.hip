@@ -56,12 +56,12 @@ triangle_kernel(const uint4 *__restrict__ alt, const double *__restrict__ fa, co
         const uint64_t te = tile_base(t + 1u, G);
         const uint64_t seg_end = b1 < te ? b1 : te;
         const uint32_t seg_len = (uint32_t)(seg_end - u);
-        __syncthreads();   // everyone is done with the previous tile
+        block_sync();   // everyone is done with the previous tile
         stage_tile(jt, alt + (size_t)t * nchunks * kSlab, nchunks * kSlab);
         const uint32_t j0 = t * kSlab + lane, j1 = j0 + 64u;
         const double fa2[2] = {fa[j0], fa[j1]};
         const double fr2[2] = {fr[j0], fr[j1]};
-        __syncthreads();
+        block_sync();
 
         for (uint32_t k = wave; k < seg_len; k += kWaves) {
             const uint64_t uu = u + k;
@@ -122,7 +122,7 @@ pair_counts_kernel(const uint4 *__restrict__ alt_i, const uint4 *__restrict__ al
     const uint32_t t = blockIdx.x;                          // j-tile
     const uint32_t groups_i = (n_i + kGroup - 1) / kGroup;  // the I plane is padded to whole slabs
     stage_tile(jt, alt_j + (size_t)t * nchunks * kSlab, nchunks * kSlab);
-    __syncthreads();
+    block_sync();
     for (uint32_t g = blockIdx.y * kWaves + wave; g < groups_i; g += gridDim.y * kWaves) {
         const uint32_t row0 = g * kGroup;
         const uint4 *ai = alt_i + ((size_t)(row0 / kSlab) * nchunks) * kSlab + (row0 % kSlab);

@@ -41,6 +41,41 @@ def test_no_torch_or_python_dependency_in_library():
     assert "torch" not in out and "libpython" not in out
 
 
+def test_every_workgroup_barrier_drains_lds_first(tmp_path):
+    """Every s_barrier in the shipped gfx950 code is preceded by s_waitcnt lgkmcnt(0) with no LDS / scalar-memory
+    instruction in between (csrc/ldx_common.h, block_sync).  hipcc leaves that wait out of a plain __syncthreads();
+    without it a pass ticket written to LDS just before the barrier was, about once in 10^6 passes, read stale by
+    another wave and one pass of a 50 000 x 1008 triangle came back miscomputed (tools/gpu_soak.py)."""
+    import shutil
+    import subprocess
+
+    from ld_tools_amd import _lib
+
+    objdump = Path("/opt/rocm/lib/llvm/bin/llvm-objdump")
+    if not objdump.exists():
+        pytest.skip("llvm-objdump not in this image")
+    shutil.copy(_lib.LIB_PATH, tmp_path / "libldx.so")            # --offloading unbundles next to its input
+    subprocess.run([str(objdump), "--offloading", "libldx.so"], cwd=tmp_path, capture_output=True, check=True)
+    objs = sorted(tmp_path.glob("libldx.so.*gfx950"))
+    assert len(objs) >= 5, "one gfx950 code object per .hip source"
+    stop = re.compile(r"(ds_|s_load|s_buffer_load|flat_|scratch_|s_cbranch|s_branch|s_setpc|s_swappc|s_endpgm)")
+    barriers = 0
+    for obj in objs:
+        text = subprocess.run([str(objdump), "-d", str(obj)], capture_output=True, text=True, check=True).stdout
+        lines = [ln.split("//")[0].strip() for ln in text.split("\n")]
+        for i, ln in enumerate(lines):
+            if not ln.startswith("s_barrier"):
+                continue
+            barriers += 1
+            j = i - 1
+            while j >= 0 and not (lines[j].startswith("s_waitcnt") and "lgkmcnt(0)" in lines[j]):
+                assert lines[j] and not lines[j].endswith(":") and not stop.match(lines[j]), \
+                    f"{obj.name}: s_barrier without a preceding s_waitcnt lgkmcnt(0): {lines[max(0, i - 6): i + 1]}"
+                j -= 1
+            assert j >= 0
+    assert barriers >= 100     # the matrix-pipe kernels alone hold > 100 (one per K-block step, unrolled by three)
+
+
 def test_geometry_helpers():
     from ld_tools_amd import _lib, dist
 
