@@ -814,19 +814,19 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 const uint32_t lane_off = halfe * 4u * kSlab + l32e;   // rows e and e + 4 of a group of 8 belong to the two lane halves
                 const float *const rt = rtab32 + halfe * 16u, *const ct = ctab32 + l32e * 4u;
                 uint32_t qn = 0;   // parked steps (wave-uniform)
+                F32Col cols[4];    // this lane's four columns: held for the sixteen steps (16 registers; no spills at 256)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) {
+                    const v4f v = *reinterpret_cast<const v4f *>(ct + 32u * tt * 4u);
+                    cols[tt] = F32Col{v.x, v.y, v.z, v.w};
+                }
 #pragma unroll 1
                 for (int e = 0; e < 16; ++e) {
                     F32Row rows[2];
-                    F32Col cols[4];
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {   // two addresses per wave: broadcast
                         const v4f v = *reinterpret_cast<const v4f *>(rt + (32u * m + (e & 3) + 8u * (e >> 2)) * 4u);
                         rows[m] = F32Row{v.x, v.y, v.z, v.w};
-                    }
-#pragma unroll
-                    for (int tt = 0; tt < 4; ++tt) {   // the column operands come from LDS every step: 16 registers not held
-                        const v4f v = *reinterpret_cast<const v4f *>(ct + 32u * tt * 4u);
-                        cols[tt] = F32Col{v.x, v.y, v.z, v.w};
                     }
                     Cell cell[8];
                     float wmax = 0.0f, ymin = 1.0f;
