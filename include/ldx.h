@@ -215,7 +215,8 @@ size_t ldx_area_workspace_bytes(uint32_t n_snps, uint32_t n_hap, uint32_t n_quer
  * sorted by (query row, opposing row) = the reference's output order (ld_area.py:152,215-217), plus the per-row index
  * offsets[n_snps + 1] (hits of query row q are sorted[offsets[q] .. offsets[q + 1])).  n_reserved: the device counter
  * ldx_area_dev filled; sorted: capacity hit_cap; summary: device uint64 [2] = {number of hits, slots reserved}.
- * If summary[1] > hit_cap the scan overflowed its buffer: run both again with hit_cap >= summary[1]. */
+ * If summary[1] > hit_cap the scan overflowed its buffer: run both again with hit_cap >= summary[1].
+ * offsets must be 16-byte aligned, workspace 256-byte aligned. */
 int ldx_area_finish_dev(const ldx_hit *raw, const uint64_t *n_reserved, uint64_t hit_cap, uint32_t n_snps,
                         ldx_hit *sorted, uint32_t *offsets, uint64_t *summary, void *workspace,
                         size_t workspace_bytes, void *stream);
