@@ -20,8 +20,9 @@ src = root / "gpurun_out" / f"prof_{tag}"
 dst = root / "profiles" / rnd
 dst.mkdir(parents=True, exist_ok=True)
 shutil.copy(src / "summary.txt", dst / f"{tag}_rocprofv3_summary.txt")
-for f in glob.glob(str(src / "trace" / "**" / "*kernel_stats.csv"), recursive=True):
-    shutil.copy(f, dst / f"{tag}_kernel_stats.csv")
+stats = sorted(glob.glob(str(src / "trace" / "**" / "*kernel_stats.csv"), recursive=True), key=lambda f: Path(f).stat().st_mtime)
+if stats:   # gpurun_out/ keeps the files of earlier runs with the same tag: the newest one is this run's
+    shutil.copy(stats[-1], dst / f"{tag}_kernel_stats.csv")
 for line in open(src / "bench_trace.log"):
     if line.startswith("{"):
         (dst / f"{tag}_bench_under_rocprof.json").write_text(line)
