@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Randomised cross-check of the matrix-pipe kernels against the AND+popcount kernels, for a bounded time.
+
+    python tools/gpu_fuzz.py [seconds] [seed]
+
+Every round draws a panel shape (SNPs 130..9000, haplotypes 16..6000, a missing-code rate, sometimes monomorphic or
+all-missing rows), packs it, and compares
+  * ld_triangle: 'fp4' and 'mfma' against 'popcount', both cell formats, with and without the n11 plane, on the whole
+    triangle and on a random unit range, each matrix-pipe launch repeated (the second launch into a poisoned buffer);
+  * ld_area: the three kernels' ordered hit lists for a random flank / measure / threshold / query subset.
+Any difference is printed with its shape and seed and the process exits 1.  The popcount kernels are the independent
+second implementation (they share no counting or staging code with the matrix-pipe kernel) and are themselves pinned to
+the oracle and the reference's golden outputs by tests/test_gpu_parity.py.
+"""
+import sys
+import time
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from ld_tools_amd import PackedPanel, ld_area, ld_triangle, ops, synth  # noqa: E402
+
+
+class Mismatch(AssertionError):
+    pass
+
+
+def run(budget: float = 120.0, seed: int = 1) -> str:
+    rng = np.random.RandomState(seed)
+    t_end = time.time() + budget
+    rounds = pairs = hits = 0
+
+    def fail(msg):
+        raise Mismatch(msg)
+
+    while time.time() < t_end:
+        n = int(rng.choice([rng.randint(130, 700), rng.randint(700, 3000), rng.randint(3000, 9000)]))
+        h = int(rng.choice([rng.randint(16, 300), rng.randint(300, 1100), rng.choice([1008, 2504, 5008, 5096]), rng.randint(1100, 6000)]))
+        miss = float(rng.choice([0.0, 0.0, 0.002, 0.05]))
+        seed = int(rng.randint(1, 1 << 30))
+        codes = synth.synth_codes_device(n, h, seed=seed, miss=miss)
+        if rng.rand() < 0.3:                                   # degenerate rows: monomorphic ALT / REF, all missing
+            for r in rng.randint(0, n, size=3):
+                codes[int(r), :h] = int(rng.choice([0, 1, 2]))
+        p = PackedPanel.from_codes(codes)
+        tag = f"n={n} h={h} miss={miss} seed={seed}"
+        for fmt in ("k16", "ld32"):
+            view = torch.int16 if fmt == "k16" else torch.int32
+            want_n11 = bool(rng.rand() < 0.3)
+            total = p.n_units
+            ur = None
+            if rng.rand() < 0.4:
+                a = int(rng.randint(0, total))
+                ur = (a, int(rng.randint(a, total + 1)))
+            ref = ld_triangle(p, fmt=fmt, path="popcount", want_n11=want_n11, unit_range=ur)
+            for path in ("fp4", "mfma"):
+                got = ld_triangle(p, fmt=fmt, path=path, want_n11=want_n11, unit_range=ur)
+                for rep in range(2):
+                    if not torch.equal(got.cells.view(view), ref.cells.view(view)):
+                        fail(f"ld_triangle {path} {fmt} n11={want_n11} unit_range={ur} launch {rep}: {tag}")
+                    if want_n11 and not torch.equal(got.n11, ref.n11):
+                        fail(f"ld_triangle n11 plane {path} {fmt} unit_range={ur}: {tag}")
+                    got.cells.view(view).fill_(-1)
+                    ld_triangle(p, fmt=fmt, path=path, want_n11=want_n11, unit_range=ur, out=got)
+            pairs += ref.cells.shape[0]
+        # ld_area
+        pos = np.cumsum(rng.choice([0, 1, 37, 800, 5000], size=n, p=[0.03, 0.27, 0.4, 0.25, 0.05])) + 1
+        flank = int(rng.choice([0, 500, 20000, 250000]))
+        measure = str(rng.choice(["r_square", "d_prime"]))
+        thres = float(rng.choice([0.0, 0.2, 0.8, 1.0]))
+        queries = None if rng.rand() < 0.5 else sorted(set(rng.randint(0, n, size=int(rng.randint(1, n))).tolist()))
+        res = {}
+        for path in ("popcount", "mfma", "fp4"):
+            ops.set_area_path(path)
+            res[path] = ld_area(p, pos, queries, flank, measure, thres)
+        ops.set_area_path("auto")
+        w = res["popcount"]
+        for path in ("mfma", "fp4"):
+            g = res[path]
+            same = (len(g) == len(w) and g.n_pairs == w.n_pairs and torch.equal(g.query, w.query) and torch.equal(g.oppos, w.oppos)
+                    and torch.equal(g.ld32.view(torch.int32), w.ld32.view(torch.int32)))
+            if not same:
+                fail(f"ld_area {path} flank={flank} {measure}>={thres} queries={'all' if queries is None else len(queries)}: {tag}")
+        hits += len(w)
+        rounds += 1
+        del p, codes, res
+    return (f"fuzz ok: {rounds} panels, {pairs} triangle cells x 2 kernels x 2 launches, {hits} ld_area hits x 2 kernels, "
+            f"{budget:.0f} s")
+
+
+if __name__ == "__main__":
+    try:
+        print(run(float(sys.argv[1]) if len(sys.argv) > 1 else 120.0, int(sys.argv[2]) if len(sys.argv) > 2 else 1))
+    except Mismatch as exc:
+        print("FUZZ MISMATCH:", exc, flush=True)
+        sys.exit(1)
