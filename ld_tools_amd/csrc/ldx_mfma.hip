@@ -211,7 +211,11 @@ struct AreaArgs {
     F32Const f32;                  // the fp32 epilogue tier's constants (triangle launches use only this member)
 };
 constexpr uint32_t kHitBatch = 256;   // hit slots a wave reserves per atomic (as in ldx_area.hip)
+#ifdef LDX_MM1   // tuning build with three workgroups per CU: 53 KB of LDS each
+constexpr uint32_t kQueueCap = 32;
+#else
 constexpr uint32_t kQueueCap = 128;   // fp32 tier: lane-steps a wave can park for the fp64 tier
+#endif
 // dynamic LDS of the kernel: the two j-tile image buffers, the fp64 operand tables, tickets, and for the FP4 triangle
 // kernel the fp32 tables and the four queues
 constexpr size_t mfma_lds_bytes(uint32_t stat_rows, bool f32_tier)
@@ -531,7 +535,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                     dst[0] = d2{r.a_s, r.ra};
                     dst[1] = d2{r.rr, r.rq_s};
                 }
-                if constexpr (kF32Tier && MM == 2) {
+                if constexpr (kF32Tier) {   // (a half-height unit's lanes 32-63 repeat rows 0-31 into slots nobody reads)
                     const F32Row r32 = f32_row(r.a_s * 1e-4, r.ra, r.rr);   // 1e4 a / 1e4: exact (a < 2^32)
                     *reinterpret_cast<v4f *>(rtab32 + lane * 4u) = v4f{r32.a, r32.ra_s, r32.rr_s, r32.s};
                 }
@@ -799,7 +803,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
             // at a time, one parked PAIR per lane: the rare path runs at full lane occupancy.  A unit that parks more steps
             // than the queue holds is redone as a whole by the fp64 epilogue (returns false).
             auto epilogue_f32 = [&]() -> bool {
-              if constexpr (kF32Tier && MM == 2) {
+              if constexpr (kF32Tier) {
                 if (ablate & 1) return true;   // tuning: no epilogue at all
                 // this unit's cells: a wave-uniform base (scalar registers) + a per-lane constant + a per-step scalar offset
                 const uint64_t ub = vv * 8u - u_begin;
@@ -813,6 +817,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 const uint32_t l32e = ln & 31u, halfe = ln >> 5;
                 const uint32_t lane_off = halfe * 4u * kSlab + l32e;   // rows e and e + 4 of a group of 8 belong to the two lane halves
                 const float *const rt = rtab32 + halfe * 16u, *const ct = ctab32 + l32e * 4u;
+                const uint32_t grp0 = roff / kGroup;   // first 8-row group of this wave's rows inside the unit (scalar)
                 uint32_t qn = 0;   // parked steps (wave-uniform)
                 F32Col cols[4];    // this lane's four columns: held for the sixteen steps (16 registers; no spills at 256)
 #pragma unroll
@@ -822,32 +827,16 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 }
 #pragma unroll 1
                 for (int e = 0; e < 16; ++e) {
-                    F32Row rows[2];
+                    F32Row rows[MM];
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) {   // two addresses per wave: broadcast
+                    for (int m = 0; m < MM; ++m) {   // two addresses per wave: broadcast
                         const v4f v = *reinterpret_cast<const v4f *>(rt + (32u * m + (e & 3) + 8u * (e >> 2)) * 4u);
                         rows[m] = F32Row{v.x, v.y, v.z, v.w};
                     }
-                    Cell cell[8];
+                    Cell cell[4 * MM];
                     float wmax = 0.0f, ymin = 1.0f;
-#ifdef LDX_F32_W8   // tuning: all eight chains of a step interleaved
-                    {
-                        float c8[8];
-                        F32Row r8[8];
-                        F32Col k8[8];
 #pragma unroll
-                        for (int g = 0; g < 2; ++g)
-#pragma unroll
-                            for (int tt = 0; tt < 4; ++tt) {
-                                c8[g * 4 + tt] = acc[g][tt][e];
-                                r8[g * 4 + tt] = rows[g];
-                                k8[g * 4 + tt] = cols[tt];
-                            }
-                        ld_multi_f32<8, Cell>(c8, fc32, r8, k8, cell, wmax, ymin);
-                    }
-#else
-#pragma unroll
-                    for (int g = 0; g < 2; ++g) {   // four interleaved chains at a time: (m, tt) = (g, 0..3)
+                    for (int g = 0; g < MM; ++g) {   // four interleaved chains at a time: (m, tt) = (g, 0..3)
                         float c4[4];
                         F32Row r4[4];
                         Cell o4[4];
@@ -860,12 +849,11 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
 #pragma unroll
                         for (int tt = 0; tt < 4; ++tt) cell[g * 4 + tt] = o4[tt];
                     }
-#endif
                     const bool sure = ((wmax < fc32.tol) & (ymin > 0.0f)) | ((ablate & 1024) != 0);   // tuning: 1024 = never park
                     if (sure && !(ablate & 4)) {
 #pragma unroll
-                        for (int m = 0; m < 2; ++m) {
-                            Cell *const row = ubase + ((4u * m + (e >> 2)) * LDX_UNIT_PAIRS + (e & 3) * kSlab);   // scalar
+                        for (int m = 0; m < MM; ++m) {   // groups of 8 rows: 4 m + e / 4 of a whole unit, 4 hsel + e / 4 of a half-height one
+                            Cell *const row = ubase + ((4u * m + grp0 + (e >> 2)) * LDX_UNIT_PAIRS + (e & 3) * kSlab);   // scalar
 #pragma unroll
                             for (int tt = 0; tt < 4; ++tt) row[lane_off + 32u * tt] = cell[m * 4 + tt];
                         }
@@ -882,8 +870,8 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                                                                               __builtin_amdgcn_mbcnt_lo((uint32_t)parked, 0u));
                             qid[pos] = ((uint32_t)e << 8) | ln;
                             v4f *dst = reinterpret_cast<v4f *>(qcnt + (size_t)pos * 8u);
-                            dst[0] = v4f{acc[0][0][e], acc[0][1][e], acc[0][2][e], acc[0][3][e]};
-                            dst[1] = v4f{acc[1][0][e], acc[1][1][e], acc[1][2][e], acc[1][3][e]};
+#pragma unroll
+                            for (int m = 0; m < MM; ++m) dst[m] = v4f{acc[m][0][e], acc[m][1][e], acc[m][2][e], acc[m][3][e]};
                         }
                         qn += np;
                     }
@@ -896,14 +884,15 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                     __builtin_amdgcn_s_waitcnt(0xC07F);   // this wave's queue writes have landed (lgkmcnt(0))
                     __builtin_amdgcn_wave_barrier();
                 }
-                // one PAIR per lane: eight lanes share a parked step (lane % 8 = 4 m + tt), so the usual handful of entries
+                // one PAIR per lane: 4 MM lanes share a parked step (lane % (4 MM) = 4 m + tt), so the usual handful of entries
                 // is one short batch at full occupancy instead of a 64-lane batch with a few busy lanes doing eight pairs each
                 // (lane-derived values recomputed from an opaque copy of the lane id, as above: hoisted out of the pass loop
                 // they would be spilled to scratch around the K loop)
                 uint32_t ld = ln;
                 asm volatile("" : "+v"(ld));
-                for (uint32_t q0 = 0; q0 < qn; q0 += 8u) {   // wave-uniform
-                    const uint32_t ent = q0 + (ld >> 3), pr = ld & 7u;
+                constexpr uint32_t kPer = 4u * MM, kShift = MM == 2 ? 3u : 2u;   // lanes per parked step
+                for (uint32_t q0 = 0; q0 < qn; q0 += 64u / kPer) {   // wave-uniform
+                    const uint32_t ent = q0 + (ld >> kShift), pr = ld & (kPer - 1u);
                     if (ent < qn) {
                         const uint32_t id = qid[ent];
                         const uint32_t e2 = id >> 8, l2 = id & 31u, h2 = (id >> 5) & 1u;
@@ -925,7 +914,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                             atomicAdd(&g_dbg[3], 1ull);
 #endif
                         }
-                        ubase[(size_t)(ri2 / kGroup) * LDX_UNIT_PAIRS + (ri2 % kGroup) * kSlab + cl] = r2[0];
+                        ubase[(size_t)(grp0 + ri2 / kGroup) * LDX_UNIT_PAIRS + (ri2 % kGroup) * kSlab + cl] = r2[0];
                     }
                 }
                 return true;
@@ -1058,7 +1047,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
             const bool clean = !kRaw && rows_ordinary && (cols_odd[0] | cols_odd[1]) == 0u &&
                                row0 >= (t + 1u) * kSlab && row0 + 32u * MM <= n_snps && (t + 1u) * kSlab <= n_snps &&
                                vv * 8u >= u_begin && vv * 8u + 8u <= u_end;
-            if constexpr (kF32Tier && MM == 2) {
+            if constexpr (kF32Tier) {
                 if (clean && !(ablate & 512)) {
                     if (!epilogue_f32()) epilogue(std::true_type{});   // queue overflow: the whole unit again, fp64
                 } else {
