@@ -12,7 +12,8 @@ import numpy as np
 
 from ..ops import ld_area
 from ..panel import PackedPanel
-from .ingest import codes_matrix, find_record, sample_genotypes
+from .ingest import RaggedGenotypesError, codes_matrix, find_record, sample_genotypes
+from .ragged import ragged_pairs
 
 HEADER_ROW = ["hg38_pos", "rsID", "ref", "alt", "type", "alt_freq", "r2", "D'", "dist"]   # ld_area.py:97-105
 _RS = re.compile(r"rs\d+$")
@@ -90,10 +91,29 @@ def area_scan(vcf, chrom, chrom_rows: Sequence[Sequence], sample_names: Sequence
             index.setdefault(key(r), k)
         q_rows = {m: index[key(queries[m])] for m in members}           # every query lies in its cluster's region
         genotypes = [sample_genotypes(r, sample_names) for r in region]
-        panel = PackedPanel.from_codes(codes_matrix(genotypes))
         positions = np.array([r.pos for r in region], dtype=np.int64)
         stops = np.array([r.pos - 1 + len(r.ref) for r in region], dtype=np.int64)
         eligible = np.array([_RS.match(r.id or "") is not None and "MULTI_ALLELIC" not in r.info for r in region])
+        try:
+            codes = codes_matrix(genotypes)
+        except RaggedGenotypesError:
+            # mixed ploidy inside this cluster: the window and the filters applied on the host, calc_ld in batches by
+            # pairs of genotype-list lengths (drivers/ragged.py: zip semantics of calc_ld.py:30-31)
+            for m in members:
+                q, qrow = queries[m], q_rows[m]
+                low, high = max(0, q.pos - flank_size), q.pos + flank_size
+                qg = genotypes[qrow]
+                res = AreaQueryResult(q.id, _ann(q) + [round(list(qg).count(1) / len(qg), 4)] + ["quer"] * 3)   # ld_area.py:188-196
+                opp = [k for k, o in enumerate(region)
+                       if eligible[k] and o.id != q.id and positions[k] - 1 < high and stops[k] > low]
+                for orow, v in zip(opp, ragged_pairs(genotypes, [(qrow, k) for k in opp])):
+                    if v[ld_thres_measure] < ld_low_thres:            # ld_area.py:248
+                        continue
+                    o = region[orow]
+                    res.hits.append(_ann(o) + [v["var_2_alt_freq"], v["r_square"], v["d_prime"], o.pos - q.pos])
+                results[m] = res
+            continue
+        panel = PackedPanel.from_codes(codes)
         # the kernel's window is positional (low < pos_o <= high); long REF alleles that start before the window but
         # overlap it are reached by widening the lower flank, and the exact overlap rule is applied to the hits below
         extra = int((stops - (positions - 1)).max()) - 1

@@ -11,9 +11,9 @@ from ..panel import encode_codes
 class RaggedGenotypesError(ValueError):
     """Variants of one panel carry different haplotype counts (mixed ploidy, e.g. chrX across the PAR boundary).
 
-    The reference would pair such lists with zip (n = the shorter one, calc_ld.py:30-31) while counting alleles
-    over the full lists; the batched kernels need one haplotype count per panel.  Use the drop-in
-    ``ld_tools_amd.backend.calc_ld.calc_ld`` pair by pair for such data.
+    The reference pairs such lists with zip (n = the shorter one, calc_ld.py:30-31) while counting alleles over the
+    full lists; one packed panel needs one haplotype count.  ``codes_matrix`` raises this; the triangle and area
+    drivers catch it and go through ``drivers/ragged.py`` (the same semantics, batched per pair of lengths).
     """
 
 

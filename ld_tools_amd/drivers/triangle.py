@@ -9,7 +9,8 @@ import numpy as np
 
 from ..ops import ld_triangle
 from ..panel import PackedPanel
-from .ingest import codes_matrix, find_record, k_to_python, sample_genotypes
+from .ingest import RaggedGenotypesError, codes_matrix, find_record, k_to_python, sample_genotypes
+from .ragged import ragged_pairs
 
 
 @dataclass
@@ -40,9 +41,23 @@ def triangle_matrix(vcf, chrom, chrom_rows: Sequence[Sequence], sample_names: Se
         genotypes.append(sample_genotypes(rec, sample_names) if rec is not None else [])
         alleles.append(rec.ref + "/" + rec.alts[0] if rec is not None else "")
         types.append(rec.info["VT"][0] if rec is not None else "")
-    panel = PackedPanel.from_codes(codes_matrix(genotypes))
-    res = ld_triangle(panel, fmt="k16")                               # 4-byte cells: k and the int-0 mark, lossless
     n = len(rows)
+    try:
+        codes = codes_matrix(genotypes)
+    except RaggedGenotypesError:
+        # mixed ploidy: genotype lists of different lengths.  The reference zips them pair by pair (calc_ld.py:30-31);
+        # drivers/ragged.py does the same in batches, one pair of length groups at a time
+        pairs = [(r, c) for r in range(n) for c in range(r)]
+        vals = ragged_pairs(genotypes, pairs)
+        ld_two_dim = [[0] * n for _ in range(n)]                      # the template of int zeros (ld_triangle.py:133-141)
+        for (r, c), v in zip(pairs, vals):
+            if ld_low_thres is not None and v[ld_measure] < ld_low_thres:
+                continue                                              # ld_triangle.py:223-225
+            ld_two_dim[r][c] = v[ld_measure]
+        alt_freqs = [round(list(g).count(1) / len(g), 4) for g in genotypes]
+        return TriangleMatrix(chrom, rs_ids, poss, ld_two_dim, alleles, types, alt_freqs)
+    panel = PackedPanel.from_codes(codes)
+    res = ld_triangle(panel, fmt="k16")                               # 4-byte cells: k and the int-0 mark, lossless
     dense, fixes = res.dense_values(ld_measure, ld_low_thres)        # -0.0 = the template's / a computed int 0
     flat = k_to_python(dense, fixes)
     ld_two_dim = [flat[r * n:(r + 1) * n] for r in range(n)]

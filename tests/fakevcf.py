@@ -33,10 +33,12 @@ class FakeVcf:
         pass
 
 
-def make_chromosome(chrom="6", n_variants=48, n_samples=40, seed=11, first_pos=1000, step=137):
+def make_chromosome(chrom="6", n_variants=48, n_samples=40, seed=11, first_pos=1000, step=137, haploid_from=None):
     """Records with LD blocks (ld_tools_amd.synth), plus the oddities the reference's filters and genotype
     assembly react to: a MULTI_ALLELIC record, a non-rs id, a duplicated rsID, a long deletion (REF of 40 bases),
-    two records at one position, a sample absent from some records, missing (None) and second-ALT (2) calls."""
+    two records at one position, a sample absent from some records, missing (None) and second-ALT (2) calls.
+    ``haploid_from``: records from that index on carry one-allele GTs for every second sample, so genotype lists of
+    two lengths meet (the reference zips them, calc_ld.py:30-31)."""
     codes = synth.synth_codes_host(n_variants, 2 * n_samples, seed=seed)
     names = [f"HG{100 + s:05d}" for s in range(n_samples)]
     rng = np.random.RandomState(seed)
@@ -68,6 +70,8 @@ def make_chromosome(chrom="6", n_variants=48, n_samples=40, seed=11, first_pos=1
                 gt[rng.randint(2)] = None
             if v == 5 and rng.rand() < 0.2:
                 gt[0] = 2
+            if haploid_from is not None and v >= haploid_from and s % 2 == 1:
+                gt = gt[:1]                     # mixed ploidy (chrX past the PAR boundary): every second sample is haploid
             samples[name] = {"GT": tuple(gt)}
         records.append(FakeRecord(chrom, pos, rs_id, ref, alts, info, samples))
     # a sample missing from SOME records would make genotype lists ragged (not supported by the batched drivers and

@@ -39,5 +39,22 @@ for ftype in ("tsv", "json", "rsids"):
     for measure, thres, flank in (("r_square", 0.8, 1000), ("d_prime", 0.9, 400), ("r_square", 0.05, 2500)):
         out["area"][f"{ftype}|{measure}|{thres}|{flank}"] = ref_loops.area_files(
             vcf, "6", queries, names, flank, measure, thres, ftype, ("ALL",), ("female",), ref_calc_ld)
+# mixed ploidy: genotype lists of two lengths in one table (the reference zips them pair by pair)
+rvcf, rnames = fakevcf.make_chromosome(haploid_from=24)
+rrows = [[r.pos, r.id] for r in rvcf.records if r.id.startswith("rs") and ";" not in r.id]
+seen, runiq = set(), []
+for r in rrows:
+    if r[1] not in seen:
+        seen.add(r[1])
+        runiq.append(r)
+out["triangle_ragged"] = {}
+out["area_ragged"] = {}
+for measure, thres in (("r_square", None), ("d_prime", 0.3)):
+    out["triangle_ragged"][f"{measure}|{thres}"] = ref_loops.triangle_tsv(
+        rvcf, "6", runiq[8:30:2], rnames, measure, thres, ("EUR",), ("male", "female"), ref_calc_ld)
+for ftype in ("tsv", "json"):
+    for measure, thres, flank in (("r_square", 0.05, 900), ("d_prime", 0.9, 2500)):
+        out["area_ragged"][f"{ftype}|{measure}|{thres}|{flank}"] = ref_loops.area_files(
+            rvcf, "6", runiq[::4], rnames, flank, measure, thres, ftype, ("ALL",), ("male", "female"), ref_calc_ld)
 (HERE / "driver_text.json").write_text(json.dumps(out, indent=0, sort_keys=True))
 print({k: {kk: (len(v) if isinstance(v, str) else len(v)) for kk, v in d.items()} for k, d in out.items()})

@@ -196,6 +196,65 @@ def test_area_driver_writes_reference_text(chrom6, tmp_path, ftype):
         get_inld_vars(lambda chrom: vcf, {"6": queries[:1]}, "q.txt", str(tmp_path / "case0"), names)
 
 
+@pytest.fixture(scope="module")
+def ragged6():
+    """Mixed ploidy: from record 24 on every second sample is haploid, so genotype lists of two lengths meet."""
+    vcf, names = fakevcf.make_chromosome(haploid_from=24)
+    uniq = _rows(vcf)
+    return vcf, names, uniq[8:30:2], uniq[::4]
+
+
+def test_restated_loops_with_oracle_match_reference_golden_ragged(ragged6):
+    """CPU: the oracle's calc_ld keeps the reference's zip semantics (n = the shorter list, allele counts over the full
+    lists, calc_ld.py:30-44) -- checked against texts made with the reference itself."""
+    vcf, names, tri_rows, queries = ragged6
+    for key, text in GOLD["triangle_ragged"].items():
+        measure, thres = key.split("|")
+        thres = None if thres == "None" else float(thres)
+        assert ref_loops.triangle_tsv(vcf, "6", tri_rows, names, measure, thres, ("EUR",), ("male", "female"),
+                                      orc.calc_ld_lists) == text
+    for key, want in GOLD["area_ragged"].items():
+        ftype, measure, thres, flank = key.split("|")
+        assert ref_loops.area_files(vcf, "6", queries, names, int(flank), measure, float(thres), ftype, ("ALL",),
+                                    ("male", "female"), orc.calc_ld_lists) == want
+
+
+@pytest.mark.gpu
+def test_drivers_mixed_ploidy_match_reference_text(ragged6, tmp_path):
+    """Genotype lists of different lengths in one table (chrX across the PAR boundary): the drivers fall back to
+    drivers/ragged.py -- pair_counts on length-truncated panels + the mirror epilogue, in batches -- and write the
+    reference's bytes (ld_triangle table; ld_area tsv / json incl. the per-pair var_2_alt_freq)."""
+    from ld_tools_amd.backend.calc_ld import calc_ld
+    from ld_tools_amd.drivers import get_inld_vars, triangle_matrix, write_triangle_table
+    from ld_tools_amd.drivers.ingest import find_record, sample_genotypes
+    from ld_tools_amd.drivers.ragged import ragged_pairs
+    vcf, names, tri_rows, queries = ragged6
+    for key, text in GOLD["triangle_ragged"].items():
+        measure, thres = key.split("|")
+        thres = None if thres == "None" else float(thres)
+        m = triangle_matrix(vcf, "6", tri_rows, names, measure, thres)
+        p = tmp_path / f"r_{measure}_{thres}.tsv"
+        write_triangle_table(str(p), m, measure, ("EUR",), ("male", "female"))
+        assert p.read_text() == text
+    for k, (key, want) in enumerate(GOLD["area_ragged"].items()):
+        ftype, measure, thres, flank = key.split("|")
+        top = tmp_path / f"ragged{k}"
+        top.mkdir()
+        written = get_inld_vars(lambda chrom: vcf, {"6": queries}, "q.txt", str(top), names, int(flank), measure,
+                                float(thres), ftype, ("ALL",), ("male", "female"))
+        got = {os.path.basename(p): Path(p).read_text() for p in written}
+        assert sorted(got) == sorted(want)
+        for name in want:
+            assert got[name] == want[name], name
+    # the batched helper against the fused drop-in, pair by pair, both orders (lengths 80/60, 60/80, 60/60, 80/80)
+    genos = [sample_genotypes(find_record(vcf, "6", pos, rid), names) for pos, rid in tri_rows]
+    assert len({len(g) for g in genos}) == 2
+    pairs = [(i, j) for i in range(len(genos)) for j in range(len(genos)) if i != j]
+    for (i, j), v in zip(pairs, ragged_pairs(genos, pairs)):
+        w = calc_ld(genos[i], genos[j])
+        assert str(v) == str(w), (i, j)
+
+
 @pytest.mark.gpu
 def test_area_driver_against_oracle_wide_window(chrom6):
     """A window that spans the whole chromosome, every record a query (incl. the MULTI_ALLELIC, non-rs and long-REF
