@@ -74,9 +74,8 @@ def make_chromosome(chrom="6", n_variants=48, n_samples=40, seed=11, first_pos=1
                 gt = gt[:1]                     # mixed ploidy (chrX past the PAR boundary): every second sample is haploid
             samples[name] = {"GT": tuple(gt)}
         records.append(FakeRecord(chrom, pos, rs_id, ref, alts, info, samples))
-    # a sample missing from SOME records would make genotype lists ragged (not supported by the batched drivers and
-    # pathological in the reference: zip truncates); drop sample 7 everywhere instead and keep it in sample_names, so
-    # the KeyError-skip path (ld_triangle.py:170-171) is exercised on every record
+    # drop sample 7 from every record and keep it in sample_names, so the KeyError-skip path (ld_triangle.py:170-171)
+    # is exercised on every record (genotype lists of different lengths are what ``haploid_from`` is for)
     for r in records:
         r.samples.pop(names[7], None)
     return FakeVcf(records), names
