@@ -442,6 +442,51 @@ def run_rank(args):
         line["other_paths"] = {f"fp4_{other}": leg("fp4", other, reps),
                                "mfma_int8": leg("mfma", fmt, reps),
                                "popcount": leg("popcount", fmt, max(5, reps // 4))}
+        # Independent batches on two streams (two result buffers): what a driver that walks chromosomes or windows gets.
+        # The workgroups of batch k + 1 start while those of batch k drain their last passes.  NOT the headline: `value`
+        # and `roofline` are one launch after the other on one stream.
+        try:
+            streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+            outs = [ld_triangle(panel, fmt=fmt), ld_triangle(panel, fmt=fmt)]
+
+            def two_streams(count):
+                cur = torch.cuda.current_stream()      # inside a capture: the capturing stream (fork / join around it)
+                for st in streams:
+                    st.wait_stream(cur)
+                for k in range(count):
+                    with torch.cuda.stream(streams[k & 1]):
+                        ld_triangle(panel, out=outs[k & 1], fmt=fmt)
+                for st in streams:
+                    cur.wait_stream(st)
+
+            two_streams(max(4, reps // 4))
+            torch.cuda.synchronize()
+            run2, how = (lambda: two_streams(reps)), "eager launches"
+            if graph is not None:           # like the headline: the launches as one HIP graph (fork / join across the streams)
+                try:
+                    g2 = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g2):
+                        two_streams(reps)
+                    g2.replay()
+                    torch.cuda.synchronize()
+                    run2, how = g2.replay, "one HIP graph"
+                except Exception:           # noqa: BLE001
+                    torch.cuda.synchronize()
+            for o in outs:
+                o.cells.fill_(-1)
+            a, c = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            run2()
+            c.record()
+            torch.cuda.synchronize()
+            ms2 = a.elapsed_time(c) / reps
+            same = all(torch.equal(o.cells.view(torch.int32), out.cells.view(torch.int32)) for o in outs)
+            line["other_paths"]["two_streams"] = {"ms_per_batch": ms2, "pairs_per_s": n_pairs / (ms2 * 1e-3), "fmt": fmt,
+                                                      "results_equal": bool(same),
+                                                      "note": f"independent batches alternating on two HIP streams, {how}"}
+            del outs
+        except Exception as exc:   # noqa: BLE001  (an extra)
+            line["other_paths"]["two_streams"] = {"error": f"{type(exc).__name__}: {exc}"}
     if world > 1 and not args.no_single_gpu_leg:
         # strong-scaling reference: the WHOLE workload on rank 0's GPU alone, a few steps (the other ranks wait)
         single = None
