@@ -6,6 +6,7 @@
 #include <stdio.h>
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
+typedef int v8i __attribute__((ext_vector_type(8)));
 
 template <int OP>
 __global__ void __launch_bounds__(512) k(int *sink, unsigned long long *cyc, int n_mfma, int n_valu, unsigned long long *simd_id)
@@ -17,11 +18,18 @@ __global__ void __launch_bounds__(512) k(int *sink, unsigned long long *cyc, int
         v16i acc[8];
         for (int i = 0; i < 8; ++i) for (int e = 0; e < 16; ++e) acc[i][e] = 0;
         v4i a = {(int)threadIdx.x, 1, 2, 3}, b = {5, (int)threadIdx.x, 7, 8};
+#ifdef FP4_MFMA
+        v8i a8 = {0x11111111, 0x22222222, 0x11111111, 0x22222222, 0, 0, 0, 0}, b8 = {0x44444444, 0x22222222, 0x44444444, 0x22222222, 0, 0, 0, 0};
+#endif
         __syncthreads();
         t0 = __builtin_amdgcn_s_memtime();
         for (int it = 0; it < n_mfma; it += 8) {
 #pragma unroll
+#ifdef FP4_MFMA
+            for (int i = 0; i < 8; ++i) asm volatile("v_mfma_f32_32x32x64_f8f6f4 %0, %1, %2, %0 cbsz:4 blgp:4" : "+v"(acc[i]) : "v"(a), "v"(b));
+#else
             for (int i = 0; i < 8; ++i) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+#endif
         }
         asm volatile("s_nop 15\n s_nop 15");
         t1 = __builtin_amdgcn_s_memtime();
