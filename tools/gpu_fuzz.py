@@ -27,9 +27,10 @@ class Mismatch(AssertionError):
     pass
 
 
-def run(budget: float = 120.0, seed: int = 1) -> str:
+def run(budget: float = 120.0, seed: int = 1, progress: float = 0.0) -> str:
     rng = np.random.RandomState(seed)
     t_end = time.time() + budget
+    t_say = time.time() + progress
     rounds = pairs = hits = 0
 
     def fail(msg):
@@ -86,13 +87,16 @@ def run(budget: float = 120.0, seed: int = 1) -> str:
         hits += len(w)
         rounds += 1
         del p, codes, res
+        if progress and time.time() >= t_say:          # a long run must not look hung
+            print(f"  ... {rounds} panels, no difference", flush=True)
+            t_say = time.time() + progress
     return (f"fuzz ok: {rounds} panels, {pairs} triangle cells x 2 kernels x 2 launches, {hits} ld_area hits x 2 kernels, "
             f"{budget:.0f} s")
 
 
 if __name__ == "__main__":
     try:
-        print(run(float(sys.argv[1]) if len(sys.argv) > 1 else 120.0, int(sys.argv[2]) if len(sys.argv) > 2 else 1))
+        print(run(float(sys.argv[1]) if len(sys.argv) > 1 else 120.0, int(sys.argv[2]) if len(sys.argv) > 2 else 1, progress=30.0))
     except Mismatch as exc:
         print("FUZZ MISMATCH:", exc, flush=True)
         sys.exit(1)
