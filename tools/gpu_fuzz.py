@@ -7,6 +7,7 @@ Every round draws a panel shape (SNPs 130..9000, haplotypes 16..6000, a missing-
 all-missing rows), packs it, and compares
   * ld_triangle: 'fp4' and 'mfma' against 'popcount', both cell formats, with and without the n11 plane, on the whole
     triangle and on a random unit range, each matrix-pipe launch repeated (the second launch into a poisoned buffer);
+  * ld_pairs, pair_counts and the fused drop-in calc_ld on random pairs against the triangle's cells and n11 plane;
   * ld_area: the three kernels' ordered hit lists for a random flank / measure / threshold / query subset.
 Any difference is printed with its shape and seed and the process exits 1.  The popcount kernels are the independent
 second implementation (they share no counting or staging code with the matrix-pipe kernel) and are themselves pinned to
@@ -20,7 +21,9 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from ld_tools_amd import PackedPanel, ld_area, ld_triangle, ops, synth  # noqa: E402
+from ld_tools_amd import PackedPanel, ld_area, ld_triangle, ops, pair_counts, synth  # noqa: E402
+from ld_tools_amd.ops import ld_pairs  # noqa: E402
+from ld_tools_amd.backend.calc_ld import calc_ld  # noqa: E402
 
 
 class Mismatch(AssertionError):
@@ -66,6 +69,31 @@ def run(budget: float = 120.0, seed: int = 1, progress: float = 0.0) -> str:
                     got.cells.view(view).fill_(-1)
                     ld_triangle(p, fmt=fmt, path=path, want_n11=want_n11, unit_range=ur, out=got)
             pairs += ref.cells.shape[0]
+        # the other entry points on the same panel: explicit pair list, rectangular counts, the fused drop-in
+        m = min(64, n * (n - 1) // 2)
+        rr = rng.randint(1, n, size=m)
+        cc = (rng.rand(m) * rr).astype(np.int64)
+        full = ld_triangle(p, fmt="k16", path="fp4", want_n11=True)
+        kk, int0, esc = full.k_and_int0(full.cell_index(rr, cc))
+        lp = ld_pairs(p, rr, cc)
+        k_exact = np.where((lp["flags"][:, None] & np.array([2, 1])) != 0, 0, lp["k"]).astype(np.float64)
+        if not np.array_equal(np.where(esc, k_exact, kk), k_exact) or not np.array_equal(int0[:, 0], (lp["flags"] & 2) != 0) \
+                or not np.array_equal(int0[:, 1], (lp["flags"] & 1) != 0):
+            fail(f"ld_pairs vs triangle cells: {tag}")
+        n11_cells = full.n11[torch.as_tensor(full.cell_index(rr, cc), device=full.n11.device)].cpu().numpy()
+        if not np.array_equal(n11_cells.view(np.uint32), lp["n11"]):
+            fail(f"ld_pairs n11 vs triangle n11 plane: {tag}")
+        blk = pair_counts(p)[torch.as_tensor(rr, device=full.n11.device), torch.as_tensor(cc, device=full.n11.device)].cpu().numpy()
+        if not np.array_equal(blk.view(np.uint32), lp["n11"]):
+            fail(f"pair_counts vs ld_pairs: {tag}")
+        host = codes[:, :h].cpu().numpy()
+        for x in range(min(3, m)):
+            res = calc_ld(host[rr[x]], host[cc[x]])
+            want = {"r_square": 0 if lp["flags"][x] & 2 else lp["k"][x, 0] / 10000.0,
+                    "d_prime": 0 if lp["flags"][x] & 1 else lp["k"][x, 1] / 10000.0}
+            if str(res["r_square"]) != str(want["r_square"]) or str(res["d_prime"]) != str(want["d_prime"]):
+                fail(f"drop-in calc_ld vs ld_pairs at ({rr[x]}, {cc[x]}): {res} {want}: {tag}")
+        del full
         # ld_area
         pos = np.cumsum(rng.choice([0, 1, 37, 800, 5000], size=n, p=[0.03, 0.27, 0.4, 0.25, 0.05])) + 1
         flank = int(rng.choice([0, 500, 20000, 250000]))
