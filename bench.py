@@ -19,9 +19,11 @@ if the child fails or overruns --deadline; under torch.distributed.run (RANK / W
 
 Timing: W warm-up steps, then --settle-steps more untimed steps (the shader clock needs tens of ms of load to settle;
 reported as config.settle_steps, and the from-idle figure is reported beside it as cold_ms_per_step), then EXACTLY K
-steps between barrier + synchronize on both sides, max over ranks.  The K steps are replayed as one HIP graph (eager
-with --no-graph; a failed capture falls back to eager, a failed child run is repeated once without the graph); the
-output is poisoned before the timed region and compared bit for bit with a separately computed result after it.
+steps between barrier + synchronize on both sides, max over ranks.  At N = 1 the K steps are replayed as one HIP graph
+(eager with --no-graph; a failed capture falls back to eager): a 0.13 ms kernel is launch-bound otherwise.  At N > 1 a
+step is milliseconds and the launches are eager unless --graph-dist asks for a captured RCCL exchange; a failed child
+run is repeated once in the plainest mode (eager, exchange not overlapped).  The output is poisoned before the timed
+region and compared bit for bit with a separately computed result after it.
 
 Prints ONE JSON line on rank 0: whole-job pairs/s, ms per step, the roofline object of the dominant kernel (HIP events
 on the launch stream, live), at N = 1 the other two kernel paths on the same workload (int8 MFMA, AND+popcount) and the
@@ -63,6 +65,8 @@ def parse(argv=None):
     ap.add_argument("--force-dist", action="store_true", help="run the sharded path (process group + all-gather) even at world 1")
     ap.add_argument("--cpu-sample-snps", type=int, default=320)
     ap.add_argument("--no-graph", action="store_true", help="launch the steps eagerly instead of replaying a HIP graph")
+    ap.add_argument("--graph-dist", action="store_true",
+                    help="N > 1: capture the K steps, RCCL exchange included, into one HIP graph (default at N > 1: eager)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1: finish each step's all-gather before its kernel instead of overlapping it with the "
                          "previous step's kernel")
@@ -110,9 +114,10 @@ def launch_ranks(args, argv) -> int:
 
     rc, out = attempt([])
     line = json_line(out)
-    if (rc != 0 or line is None) and not args.no_graph:
-        print(f"[bench] rank processes failed (rc {rc}); once more with eager launches instead of the HIP graph", file=sys.stderr)
-        rc, out = attempt(["--no-graph"])
+    if (rc != 0 or line is None) and not (args.no_graph and args.no_overlap):
+        print(f"[bench] rank processes failed (rc {rc}); once more in the plainest mode: eager launches, exchange not "
+              "overlapped", file=sys.stderr)
+        rc, out = attempt(["--no-graph", "--no-overlap"])
         line = json_line(out)
     if line is None:
         sys.stdout.write(out)
@@ -284,7 +289,9 @@ def run_rank(args):
     # handful of small copies): a launch-bound inner loop, captured once into a HIP graph and replayed inside the
     # timed region; any failure to capture falls back to eager launches.
     graph = None
-    if not args.no_graph and (not use_dist or args.backend == "nccl"):   # RCCL collectives capture; gloo ones do not
+    # N = 1: always (a 0.13 ms kernel is launch-bound).  N > 1: a step is milliseconds, eager launches cost nothing, and a
+    # captured RCCL exchange is one more thing that can go wrong on a node this code has never met: only on request.
+    if not args.no_graph and (not use_dist or (args.graph_dist and args.backend == "nccl")):
         try:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):

@@ -40,4 +40,4 @@ def test_bench_launcher_fails_loudly_without_gpu():
                        cwd=str(ROOT))
     assert r.returncode != 0
     assert '"metric"' not in r.stdout
-    assert "needs a HIP device" in r.stderr and "once more with eager launches" in r.stderr
+    assert "needs a HIP device" in r.stderr and "once more in the plainest mode" in r.stderr
