@@ -62,7 +62,7 @@ def triangle_parser():
     p.add_argument("-q", "--square-shape", dest="square_shape", action="store_true", help="(heat maps are not produced by this build)")
     p.add_argument("-s", "--dont-disp-footer", dest="dont_disp_footer", action="store_true", help="(heat maps are not produced by this build)")
     p.add_argument("-p", "--max-proc-quan", metavar="[4]", default=4, dest="max_proc_quan", type=int,
-                   help="Maximum number of tables to be processed in parallel (accepted; tables run one after another on the GPU)")
+                   help="Maximum number of tables to be processed in parallel (worker threads of this process, one HIP stream each)")
     return p
 
 
@@ -80,7 +80,7 @@ def area_parser():
     p.add_argument("-o", "--trg-file-type", metavar="[tsv]", choices=["tsv", "json", "rsids"], default="tsv",
                    dest="trg_file_type", type=str, help="{tsv, json, rsids} Format of target files")
     p.add_argument("-p", "--max-proc-quan", metavar="[4]", default=4, dest="max_proc_quan", type=int,
-                   help="Maximum number of tables to be processed in parallel (accepted; tables run one after another on the GPU)")
+                   help="Maximum number of tables to be processed in parallel (worker threads of this process, one HIP stream each)")
     return p
 
 
@@ -138,6 +138,38 @@ def _src_files(args):
     return src_dir_path, trg, sorted(os.listdir(src_dir_path))
 
 
+def _proc_quan(max_proc_quan: int, src_files_quan: int) -> int:
+    """The reference's worker-count rule (ld_triangle.py:394-399, ld_area.py:325-330)."""
+    if max_proc_quan > src_files_quan <= 8:
+        return max(1, src_files_quan)
+    if max_proc_quan > 8:
+        return 8
+    return max(1, max_proc_quan)
+
+
+def _run_tables(src_file_names, one_table, proc_quan: int) -> None:
+    """The reference maps its tables over a process pool (ld_triangle.py:406-409).  Here the pool is threads of THIS
+    process, each with its own HIP stream: reading and parsing the VCF windows of one table overlaps the kernels of
+    another, and kernels of different tables overlap each other (the library is re-entrant, its scheduler state is
+    per stream; HIP must not be forked).  Exceptions of a worker propagate, as from Pool.map."""
+    if proc_quan <= 1 or len(src_file_names) <= 1:
+        for name in src_file_names:
+            one_table(name)
+        return
+    from concurrent.futures import ThreadPoolExecutor
+
+    import torch
+
+    def on_own_stream(name):
+        with torch.cuda.stream(torch.cuda.Stream()):
+            one_table(name)
+            torch.cuda.current_stream().synchronize()
+
+    with ThreadPoolExecutor(max_workers=proc_quan) as pool:
+        for _ in pool.map(on_own_stream, src_file_names):
+            pass
+
+
 def ld_triangle_main(argv=None):
     from .backend.create_src_dict import create_src_dict
     from .backend.get_sample_names import get_sample_names
@@ -149,12 +181,16 @@ def ld_triangle_main(argv=None):
     sample_names = get_sample_names(gend_names, pop_names, db)
     src_dir_path, trg_top, src_file_names = _src_files(args)
     opener = _vcf_opener(intgen_dir_path)
-    print(f"\nLD matrices building\n\tquantity of parallel processes: 1 (GPU)")
+    proc_quan = _proc_quan(args.max_proc_quan, len(src_file_names))
+    print(f"\nLD matrices building\n\tquantity of parallel workers (threads, one HIP stream each): {proc_quan}")
     t0 = datetime.datetime.now()
-    for name in src_file_names:
+
+    def one_table(name):
         data = create_src_dict(src_dir_path, name, args.meta_lines_quan, db)
         create_matrix(opener, data, name, trg_top, sample_names, args.ld_measure, args.ld_low_thres, args.matrix_type,
                       pop_names, gend_names)
+
+    _run_tables(src_file_names, one_table, proc_quan)
     print(f"\tparallel computation time: {datetime.datetime.now() - t0}")
 
 
@@ -169,12 +205,16 @@ def ld_area_main(argv=None):
     sample_names = get_sample_names(gend_names, pop_names, db)
     src_dir_path, trg_top, src_file_names = _src_files(args)
     opener = _vcf_opener(intgen_dir_path)
-    print(f"\nSearching for variants in LD\n\tquantity of parallel processes: 1 (GPU)")
+    proc_quan = _proc_quan(args.max_proc_quan, len(src_file_names))
+    print(f"\nSearching for variants in LD\n\tquantity of parallel workers (threads, one HIP stream each): {proc_quan}")
     t0 = datetime.datetime.now()
-    for name in src_file_names:
+
+    def one_table(name):
         data = create_src_dict(src_dir_path, name, args.meta_lines_quan, db)
         get_inld_vars(opener, data, name, trg_top, sample_names, args.flank_size, args.ld_thres_measure,
                       args.ld_low_thres, args.trg_file_type, pop_names, gend_names)
+
+    _run_tables(src_file_names, one_table, proc_quan)
     print(f"\tparallel computation time: {datetime.datetime.now() - t0}")
 
 

@@ -347,6 +347,35 @@ def test_ld_triangle_shell_end_to_end(chrom6, tmp_path):
 
 
 @pytest.mark.gpu
+def test_shells_run_several_tables_on_parallel_workers(chrom6, tmp_path):
+    """-p / --max-proc-quan (ld_triangle.py:390-411): the reference maps its tables over a process pool; here the workers are
+    threads of one process with a HIP stream each.  Five tables through 4 workers produce, file by file, the bytes of a
+    one-worker run; the worker count follows the reference's rule (min of -p, the number of tables, 8)."""
+    from ld_tools_amd.cli import _proc_quan
+    assert [_proc_quan(4, 2), _proc_quan(4, 9), _proc_quan(16, 9), _proc_quan(16, 3), _proc_quan(1, 5)] == [2, 4, 8, 3, 1]
+    vcf, names, tri_rows, queries = chrom6
+    intgen = _intgen_folder(tmp_path, vcf, names, ["male", "female"])
+    src = tmp_path / "src"
+    src.mkdir()
+    for k in range(5):
+        rows = tri_rows[k:k + 9] if k else tri_rows
+        (src / f"table{k}.tsv").write_text("h\n" + "".join(f"{rs}\tx\n" for _, rs in rows))
+    trees = {}
+    for workers in ("1", "4"):
+        for script, extra in (("ld_triangle.py", ["-l", "d_prime", "-z", "0.3", "-o", "table"]),
+                              ("ld_area.py", ["-w", "2500", "-l", "r_square", "-z", "0.05", "-o", "tsv"])):
+            trg = tmp_path / f"out_{script[:-3]}_{workers}"
+            trg.mkdir()
+            out = _run_shell(script, ["-S", str(src), "-D", str(intgen), "-t", str(trg), "-m", "1", "-f", "-e", "eur,amr",
+                                      "-p", workers] + extra, tmp_path)
+            assert f"one HIP stream each): {workers}" in out
+            trees[(script, workers)] = {str(p.relative_to(trg)): p.read_text() for p in trg.rglob("*") if p.is_file()}
+    for script in ("ld_triangle.py", "ld_area.py"):
+        assert trees[(script, "1")] and trees[(script, "1")] == trees[(script, "4")]
+    assert trees[("ld_triangle.py", "4")]["table0_LD_matr/table0_chr6_d.tsv"] == GOLD["triangle"]["d_prime|0.3"]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("ftype", ["tsv", "json", "rsids"])
 def test_ld_area_shell_end_to_end(chrom6, tmp_path, ftype):
     """`python3 ld_area.py -S ... -D ... -f -w ... -z ... -o ...`: folder tree {table}_in_LD/{chrom}/ and every file's bytes
