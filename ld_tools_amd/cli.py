@@ -7,10 +7,11 @@ What differs from the reference's scripts, on purpose:
   * the 1000 Genomes download / indexing / conversion.db build (backend/prep_intgen_data.py) is not part of this
     package: the folder must already hold ``{chrom}.vcf.gz`` (+ .tbi) and ``conversion.db``; without ``-f`` the
     shells only check that they exist;
-  * source tables are processed one after another on the GPU instead of in a multiprocessing.Pool
-    (ld_triangle.py:390-411): a table takes milliseconds of kernel time, and HIP must not be forked;
+  * source tables are processed by worker THREADS of this process, one HIP stream each, instead of a
+    multiprocessing.Pool (ld_triangle.py:390-411): same worker-count rule for -p; HIP must not be forked;
   * ld_triangle writes the tabular matrix; the plotly heat map (ld_triangle.py:239-340) is not produced;
-  * help texts are English only (the reference picks Russian by locale, ld_triangle.py:386-389).
+  * help texts are this package's own, in English or Russian; the language follows the locale like the reference's
+    (ld_triangle.py:386-389) but never fails on an unset locale (LDX_LANG=en|ru overrides).
 pysam is imported here and nowhere else in the package.
 """
 from __future__ import annotations
@@ -24,71 +25,93 @@ from argparse import ArgumentParser, RawTextHelpFormatter
 __version__ = "V11.2-ldx"
 
 
+def _lang() -> str:
+    """'ru' when the user's locale is Russian, else 'en'.  The reference indexes locale.getdefaultlocale()[0][:2]
+    (ld_triangle.py:386), which raises when no locale is set; here every source may be missing."""
+    forced = os.environ.get("LDX_LANG", "").lower()
+    if forced in ("en", "ru"):
+        return forced
+    names = [os.environ.get(v) for v in ("LC_ALL", "LC_MESSAGES", "LANG")]
+    try:
+        import locale
+        names.append(locale.getlocale()[0])
+    except Exception:   # noqa: BLE001  (a broken locale setting must not break --help)
+        pass
+    for n in names:
+        if n:
+            return "ru" if n.lower().startswith("ru") else "en"
+    return "en"
+
+
+def _t(en: str, ru: str) -> str:
+    return ru if _lang() == "ru" else en
+
+
 def _common(argparser, with_src=True):
     if with_src:
         argparser.add_argument("-S", "--src-dir-path", metavar="str", dest="src_dir_path", type=str,
-                               help="Folder that holds the input tables (one job per table)")
+                               help=_t("Folder that holds the input tables (one job per table)", "Папка с входными таблицами (каждая таблица — отдельное задание)"))
     argparser.add_argument("-D", "--intgen-dir-path", metavar="str", dest="intgen_dir_path", type=str,
-                           help="Folder with the prepared 1000 Genomes files (per-chromosome VCFs, conversion.db)")
+                           help=_t("Folder with the prepared 1000 Genomes files (per-chromosome VCFs, conversion.db)", "Папка с подготовленными файлами 1000 Genomes (VCF по хромосомам, conversion.db)"))
     if with_src:
         argparser.add_argument("-t", "--trg-top-dir-path", metavar="[None]", dest="trg_top_dir_path", type=str,
-                               help="Where result folders are created (if omitted: next to the input tables)")
+                               help=_t("Where result folders are created (if omitted: next to the input tables)", "Где создавать папки с результатами (по умолчанию — рядом с входными таблицами)"))
         argparser.add_argument("-m", "--meta-lines-quan", metavar="[0]", default=0, dest="meta_lines_quan", type=int,
-                               help="How many leading lines of each table to skip (headers, comments)")
+                               help=_t("How many leading lines of each table to skip (headers, comments)", "Сколько начальных строк каждой таблицы пропустить (заголовки, комментарии)"))
     argparser.add_argument("-f", "--skip-intgen-data-ver", dest="skip_intgen_data_ver", action="store_true",
-                           help="Trust the 1000 Genomes folder as it is and go straight to the LD computation")
+                           help=_t("Trust the 1000 Genomes folder as it is and go straight to the LD computation", "Не проверять папку 1000 Genomes, сразу перейти к расчёту LD"))
     argparser.add_argument("-g", "--gend-names", metavar="[both]", choices=["male", "female", "both"], default="both",
                            dest="gend_names", type=str,
-                           help="{male, female, both} Which samples to use, by gender")
+                           help=_t("{male, female, both} Which samples to use, by gender", "{male, female, both} Каких индивидов брать: по полу"))
     argparser.add_argument("-e", "--pop-names", metavar="[all]", default="all", dest="pop_names", type=str,
-                           help="Which samples to use, by population / super-population codes: a comma-separated list, no blanks")
+                           help=_t("Which samples to use, by population / super-population codes: a comma-separated list, no blanks", "Каких индивидов брать: коды популяций / суперпопуляций через запятую, без пробелов"))
 
 
 def triangle_parser():
     """cli/ld_triangle_cli_en.py:40-74 -- same flags, dests, defaults and choices."""
-    p = ArgumentParser(description=f"Builds LD matrices for all pairs of each set of variants (tables). Version: {__version__}",
+    p = ArgumentParser(description=_t("Builds LD matrices for all pairs of each set of variants (tables).", "Строит матрицы LD для всех пар вариантов каждого набора (таблицы).") + f" Version: {__version__}",
                        formatter_class=RawTextHelpFormatter)
     _common(p)
     p.add_argument("-l", "--ld-measure", metavar="[r_square]", choices=["r_square", "d_prime"], default="r_square",
-                   dest="ld_measure", type=str, help="{r_square, d_prime} LD measure for building matrices and for the lower threshold")
+                   dest="ld_measure", type=str, help=_t("{r_square, d_prime} LD measure for building matrices and for the lower threshold", "{r_square, d_prime} Мера LD для матриц и для нижнего порога"))
     p.add_argument("-z", "--ld-low-thres", metavar="[None]", dest="ld_low_thres", type=float,
-                   help="Lower LD threshold (subthreshold values will be zeroed)")
+                   help=_t("Lower LD threshold (subthreshold values will be zeroed)", "Нижний порог LD (значения ниже порога заменяются нулём)"))
     p.add_argument("-o", "--matrix-type", metavar="[heatmap]", choices=["heatmap", "table", "both"], default="heatmap",
-                   dest="matrix_type", type=str, help="{heatmap, table, both} Type of LD value matrices (this build writes the table)")
-    p.add_argument("-j", "--heatmap-json", dest="heatmap_json", action="store_true", help="(heat maps are not produced by this build)")
-    p.add_argument("-i", "--disp-letters", dest="disp_letters", action="store_true", help="(heat maps are not produced by this build)")
-    p.add_argument("-c", "--color-pal", metavar="[greens]", default="greens", dest="color_pal", type=str, help="(heat maps are not produced by this build)")
-    p.add_argument("-k", "--font-size", metavar="[None]", dest="font_size", type=int, help="(heat maps are not produced by this build)")
-    p.add_argument("-q", "--square-shape", dest="square_shape", action="store_true", help="(heat maps are not produced by this build)")
-    p.add_argument("-s", "--dont-disp-footer", dest="dont_disp_footer", action="store_true", help="(heat maps are not produced by this build)")
+                   dest="matrix_type", type=str, help=_t("{heatmap, table, both} Type of LD value matrices (this build writes the table)", "{heatmap, table, both} Вид матриц LD (эта сборка пишет таблицу)"))
+    p.add_argument("-j", "--heatmap-json", dest="heatmap_json", action="store_true", help=_t("(heat maps are not produced by this build)", "(тепловые карты эта сборка не строит)"))
+    p.add_argument("-i", "--disp-letters", dest="disp_letters", action="store_true", help=_t("(heat maps are not produced by this build)", "(тепловые карты эта сборка не строит)"))
+    p.add_argument("-c", "--color-pal", metavar="[greens]", default="greens", dest="color_pal", type=str, help=_t("(heat maps are not produced by this build)", "(тепловые карты эта сборка не строит)"))
+    p.add_argument("-k", "--font-size", metavar="[None]", dest="font_size", type=int, help=_t("(heat maps are not produced by this build)", "(тепловые карты эта сборка не строит)"))
+    p.add_argument("-q", "--square-shape", dest="square_shape", action="store_true", help=_t("(heat maps are not produced by this build)", "(тепловые карты эта сборка не строит)"))
+    p.add_argument("-s", "--dont-disp-footer", dest="dont_disp_footer", action="store_true", help=_t("(heat maps are not produced by this build)", "(тепловые карты эта сборка не строит)"))
     p.add_argument("-p", "--max-proc-quan", metavar="[4]", default=4, dest="max_proc_quan", type=int,
-                   help="Maximum number of tables to be processed in parallel (worker threads of this process, one HIP stream each)")
+                   help=_t("Maximum number of tables to be processed in parallel (worker threads of this process, one HIP stream each)", "Сколько таблиц обрабатывать одновременно (рабочие потоки этого процесса, у каждого свой HIP-поток)"))
     return p
 
 
 def area_parser():
     """cli/ld_area_cli_en.py:36-60"""
-    p = ArgumentParser(description=f"Finds variants in LD with the requested ones within flanks. Version: {__version__}",
+    p = ArgumentParser(description=_t("Finds variants in LD with the requested ones within flanks.", "Ищет в пределах фланков варианты, сцепленные с запрашиваемыми.") + f" Version: {__version__}",
                        formatter_class=RawTextHelpFormatter)
     _common(p)
     p.add_argument("-w", "--flank-size", metavar="[100000]", default=100000, dest="flank_size", type=int,
-                   help="Size of each flank around each query variant within which LD is calculated")
+                   help=_t("Size of each flank around each query variant within which LD is calculated", "Размер каждого фланка вокруг запрашиваемого варианта, в пределах которого считается LD"))
     p.add_argument("-l", "--ld-thres-measure", metavar="[r_square]", choices=["r_square", "d_prime"], default="r_square",
-                   dest="ld_thres_measure", type=str, help="{r_square, d_prime} LD measure for setting the lower threshold")
+                   dest="ld_thres_measure", type=str, help=_t("{r_square, d_prime} LD measure for setting the lower threshold", "{r_square, d_prime} Мера LD, по которой задаётся нижний порог"))
     p.add_argument("-z", "--ld-low-thres", metavar="[0.8]", default=0.8, dest="ld_low_thres", type=float,
-                   help="Lower LD threshold")
+                   help=_t("Lower LD threshold", "Нижний порог LD"))
     p.add_argument("-o", "--trg-file-type", metavar="[tsv]", choices=["tsv", "json", "rsids"], default="tsv",
-                   dest="trg_file_type", type=str, help="{tsv, json, rsids} Format of target files")
+                   dest="trg_file_type", type=str, help=_t("{tsv, json, rsids} Format of target files", "{tsv, json, rsids} Формат выходных файлов"))
     p.add_argument("-p", "--max-proc-quan", metavar="[4]", default=4, dest="max_proc_quan", type=int,
-                   help="Maximum number of tables to be processed in parallel (worker threads of this process, one HIP stream each)")
+                   help=_t("Maximum number of tables to be processed in parallel (worker threads of this process, one HIP stream each)", "Сколько таблиц обрабатывать одновременно (рабочие потоки этого процесса, у каждого свой HIP-поток)"))
     return p
 
 
 def lite_parser():
     """cli/ld_lite_cli_en.py:37-49"""
-    p = ArgumentParser(description=f"Prints LD of a pair of variants. Version: {__version__}", formatter_class=RawTextHelpFormatter)
-    p.add_argument("rs_id_1", metavar="rs_id_1", type=str, help="Reference SNP ID of the first variant")
-    p.add_argument("rs_id_2", metavar="rs_id_2", type=str, help="Reference SNP ID of the second variant")
+    p = ArgumentParser(description=_t("Prints LD of a pair of variants.", "Выводит LD пары вариантов.") + f" Version: {__version__}", formatter_class=RawTextHelpFormatter)
+    p.add_argument("rs_id_1", metavar="rs_id_1", type=str, help=_t("Reference SNP ID of the first variant", "rsID первого варианта"))
+    p.add_argument("rs_id_2", metavar="rs_id_2", type=str, help=_t("Reference SNP ID of the second variant", "rsID второго варианта"))
     _common(p, with_src=False)
     return p
 

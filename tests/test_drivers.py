@@ -79,6 +79,24 @@ def test_cli_surface_matches_reference():
     assert cli._names(a) == (("male",), ("EUR", "AMR"))      # ld_triangle.py:33-38
 
 
+def test_cli_language_follows_the_locale_and_survives_none(monkeypatch):
+    """ld_triangle.py:386-389 picks the Russian help when the locale starts with 'ru' and raises on an unset locale; the
+    shells here pick the same way from LC_ALL / LC_MESSAGES / LANG / locale.getlocale() and fall back to English."""
+    from ld_tools_amd import cli
+    for var in ("LDX_LANG", "LC_ALL", "LC_MESSAGES", "LANG"):
+        monkeypatch.delenv(var, raising=False)
+    monkeypatch.setattr("locale.getlocale", lambda *a: (None, None))
+    assert cli._lang() == "en"
+    monkeypatch.setenv("LANG", "ru_RU.UTF-8")
+    assert cli._lang() == "ru"
+    ru, en_dests = cli.area_parser(), None
+    monkeypatch.setenv("LDX_LANG", "en")
+    en = cli.area_parser()
+    assert [a.dest for a in ru._actions] == [a.dest for a in en._actions]          # same surface in both languages
+    assert [a.default for a in ru._actions] == [a.default for a in en._actions]
+    assert any("порог" in (a.help or "") for a in ru._actions) and all("порог" not in (a.help or "") for a in en._actions)
+
+
 def test_sample_and_source_lookups(tmp_path):
     from ld_tools_amd.backend.create_src_dict import create_src_dict
     from ld_tools_amd.backend.get_sample_names import get_sample_names
