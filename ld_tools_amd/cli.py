@@ -183,10 +183,16 @@ def _run_tables(src_file_names, one_table, proc_quan: int) -> None:
 
     import torch
 
+    import threading
+
+    local = threading.local()
+
     def on_own_stream(name):
-        with torch.cuda.stream(torch.cuda.Stream()):
+        if not hasattr(local, "stream"):
+            local.stream = torch.cuda.Stream()             # one stream per worker thread, for all its tables
+        with torch.cuda.stream(local.stream):
             one_table(name)
-            torch.cuda.current_stream().synchronize()
+            local.stream.synchronize()
 
     with ThreadPoolExecutor(max_workers=proc_quan) as pool:
         for _ in pool.map(on_own_stream, src_file_names):
