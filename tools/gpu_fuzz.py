@@ -3,7 +3,7 @@
 
     python tools/gpu_fuzz.py [seconds] [seed]
 
-Every round draws a panel shape (SNPs 130..9000, haplotypes 16..6000, a missing-code rate, sometimes monomorphic or
+Every round draws a panel shape (SNPs 2..9000, haplotypes 16..6000, a missing-code rate, sometimes monomorphic or
 all-missing rows), packs it, and compares
   * ld_triangle: 'fp4' and 'mfma' against 'popcount', both cell formats, with and without the n11 plane, on the whole
     triangle and on a random unit range, each matrix-pipe launch repeated (the second launch into a poisoned buffer);
@@ -40,7 +40,7 @@ def run(budget: float = 120.0, seed: int = 1, progress: float = 0.0) -> str:
         raise Mismatch(msg)
 
     while time.time() < t_end:
-        n = int(rng.choice([rng.randint(130, 700), rng.randint(700, 3000), rng.randint(3000, 9000)]))
+        n = int(rng.choice([rng.randint(2, 130), rng.randint(130, 700), rng.randint(700, 3000), rng.randint(3000, 9000)]))
         h = int(rng.choice([rng.randint(16, 300), rng.randint(300, 1100), rng.choice([1008, 2504, 5008, 5096]), rng.randint(1100, 6000)]))
         miss = float(rng.choice([0.0, 0.0, 0.002, 0.05]))
         seed = int(rng.randint(1, 1 << 30))
@@ -70,7 +70,7 @@ def run(budget: float = 120.0, seed: int = 1, progress: float = 0.0) -> str:
                     ld_triangle(p, fmt=fmt, path=path, want_n11=want_n11, unit_range=ur, out=got)
             pairs += ref.cells.shape[0]
         # the other entry points on the same panel: explicit pair list, rectangular counts, the fused drop-in
-        m = min(64, n * (n - 1) // 2)
+        m = max(1, min(64, n * (n - 1) // 2))
         rr = rng.randint(1, n, size=m)
         cc = (rng.rand(m) * rr).astype(np.int64)
         full = ld_triangle(p, fmt="k16", path="fp4", want_n11=True)
@@ -99,7 +99,7 @@ def run(budget: float = 120.0, seed: int = 1, progress: float = 0.0) -> str:
         flank = int(rng.choice([0, 500, 20000, 250000]))
         measure = str(rng.choice(["r_square", "d_prime"]))
         thres = float(rng.choice([0.0, 0.2, 0.8, 1.0]))
-        queries = None if rng.rand() < 0.5 else sorted(set(rng.randint(0, n, size=int(rng.randint(1, n))).tolist()))
+        queries = None if rng.rand() < 0.5 else sorted(set(rng.randint(0, n, size=int(rng.randint(1, n + 1))).tolist()))
         res = {}
         for path in ("popcount", "mfma", "fp4"):
             ops.set_area_path(path)
