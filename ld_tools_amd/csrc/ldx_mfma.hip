@@ -232,6 +232,17 @@ constexpr uint32_t kStatRows = 32;
 constexpr int kWgPerCu = 2;
 constexpr uint32_t kStatRows = kRows64;
 #endif
+// Result cells are written once and never read back by the kernel: non-temporal stores (the `nt` bit) keep them from
+// displacing the bit planes in the L2s.  Measured: -3.4 % at 50 000 x 1008 (the write-heavy shape), -0.9 % at 40 000 x 5008.
+template <typename Cell>
+__device__ __forceinline__ void store_cell(Cell *p, Cell v)
+{
+    if constexpr (sizeof(Cell) == 4)
+        __builtin_nontemporal_store(__builtin_bit_cast(uint32_t, v), reinterpret_cast<uint32_t *>(p));
+    else
+        __builtin_nontemporal_store(__builtin_bit_cast(unsigned long long, v), reinterpret_cast<unsigned long long *>(p));
+}
+
 // kFp4: the counting runs on v_mfma_f32_32x32x64_f8f6f4 with FP4 operands (expand32_a4 / expand32_b4) instead of
 // v_mfma_i32_32x32x32_i8: a K-block is then 256 haplotypes -- two 128-haplotype chunks, one per lane half -- in four
 // steps of 64, so the loop below keeps its shape (per step 8 MFMAs, 4 fragment reads, one quarter of the thread's share
@@ -788,7 +799,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                             const size_t o = (size_t)(us[m] - u_begin) * LDX_UNIT_PAIRS + (size_t)((ri[m] + roff) % kGroup) * kSlab + jl;
                             Cell w = res[m][tt];
                             if (!kClean && !valid[m][tt]) w = zero_cell<Cell>();
-                            out[o] = w;
+                            store_cell(out + o, w);
                             if (kRaw) raw[o] = rw[m][tt];
                             if (kN11) n11[o] = valid[m][tt] ? count_of(acc[m][tt][e]) : 0u;
                         }
@@ -855,7 +866,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                         for (int m = 0; m < MM; ++m) {   // groups of 8 rows: 4 m + e / 4 of a whole unit, 4 hsel + e / 4 of a half-height one
                             Cell *const row = ubase + ((4u * m + grp0 + (e >> 2)) * LDX_UNIT_PAIRS + (e & 3) * kSlab);   // scalar
 #pragma unroll
-                            for (int tt = 0; tt < 4; ++tt) row[lane_off + 32u * tt] = cell[m * 4 + tt];
+                            for (int tt = 0; tt < 4; ++tt) store_cell(row + lane_off + 32u * tt, cell[m * 4 + tt]);
                         }
                     }
                     const unsigned long long parked = __ballot(!sure);
