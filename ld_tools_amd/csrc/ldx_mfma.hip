@@ -243,6 +243,19 @@ __device__ __forceinline__ void store_cell(Cell *p, Cell v)
         __builtin_nontemporal_store(__builtin_bit_cast(unsigned long long, v), reinterpret_cast<unsigned long long *>(p));
 }
 
+// The same store with a SCALAR base and a 32-bit per-lane byte offset (`global_store_dword voff, vdata, s[base:base+1]`):
+// half the address registers the 64-bit-vaddr form reads (hipcc does not select this form for these stores by itself):
+// -1 % on every shape.  Inline asm: the compiler's own vmcnt bookkeeping does not see these stores, which only makes its
+// later waits stricter than they need be (a store returns nothing to wait for).
+template <int kOffset, typename Cell>
+__device__ __forceinline__ void store_cell_saddr(Cell *sbase, uint32_t voff_bytes, Cell v)
+{
+    if constexpr (sizeof(Cell) == 4)
+        asm volatile("global_store_dword %0, %1, %2 offset:%3 nt" : : "v"(voff_bytes), "v"(__builtin_bit_cast(uint32_t, v)), "s"(sbase), "n"(kOffset) : "memory");
+    else
+        asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3 nt" : : "v"(voff_bytes), "v"(__builtin_bit_cast(unsigned long long, v)), "s"(sbase), "n"(kOffset) : "memory");
+}
+
 // kFp4: the counting runs on v_mfma_f32_32x32x64_f8f6f4 with FP4 operands (expand32_a4 / expand32_b4) instead of
 // v_mfma_i32_32x32x32_i8: a K-block is then 256 haplotypes -- two 128-haplotype chunks, one per lane half -- in four
 // steps of 64, so the loop below keeps its shape (per step 8 MFMAs, 4 fragment reads, one quarter of the thread's share
@@ -827,6 +840,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 asm volatile("" : "+v"(ln));
                 const uint32_t l32e = ln & 31u, halfe = ln >> 5;
                 const uint32_t lane_off = halfe * 4u * kSlab + l32e;   // rows e and e + 4 of a group of 8 belong to the two lane halves
+                const uint32_t lane_off_b = lane_off * (uint32_t)sizeof(Cell);
                 const float *const rt = rtab32 + halfe * 16u, *const ct = ctab32 + l32e * 4u;
                 const uint32_t grp0 = roff / kGroup;   // first 8-row group of this wave's rows inside the unit (scalar)
                 uint32_t qn = 0;   // parked steps (wave-uniform)
@@ -866,7 +880,12 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                         for (int m = 0; m < MM; ++m) {   // groups of 8 rows: 4 m + e / 4 of a whole unit, 4 hsel + e / 4 of a half-height one
                             Cell *const row = ubase + ((4u * m + grp0 + (e >> 2)) * LDX_UNIT_PAIRS + (e & 3) * kSlab);   // scalar
 #pragma unroll
-                            for (int tt = 0; tt < 4; ++tt) store_cell(row + lane_off + 32u * tt, cell[m * 4 + tt]);
+                            for (int tt = 0; tt < 4; ++tt) {   // scalar row base + this lane's byte offset + the column tile's constant
+                                if (tt == 0) store_cell_saddr<0>(row, lane_off_b, cell[m * 4 + 0]);
+                                if (tt == 1) store_cell_saddr<32 * (int)sizeof(Cell)>(row, lane_off_b, cell[m * 4 + 1]);
+                                if (tt == 2) store_cell_saddr<64 * (int)sizeof(Cell)>(row, lane_off_b, cell[m * 4 + 2]);
+                                if (tt == 3) store_cell_saddr<96 * (int)sizeof(Cell)>(row, lane_off_b, cell[m * 4 + 3]);
+                            }
                         }
                     }
                     const unsigned long long parked = __ballot(!sure);
