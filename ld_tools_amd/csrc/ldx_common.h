@@ -422,15 +422,23 @@ __device__ __forceinline__ float f32_k_to_value(float k)
 // W pairs, stage by stage.  cnt: n11 as floats; out: the encoded cells (valid where the lane turns out sure);
 // wmax / ymin accumulate the margin quantity and the smallest y_d over the pairs of a step (the caller tests
 // wmax < tol and ymin > 0 once per step).
-template <int W, typename Cell>
+// kSmallN (n <= 4096: f32_small_n): a1 a2 <= 2^24 is exact in float32, so the product needs no error term and
+// Dn = fl(n c - p) is exact in one fma -- two instructions per pair less (of 24).
+__host__ __device__ inline bool f32_small_n(double n) { return n <= 4096.0; }
+
+template <int W, typename Cell, bool kSmallN = false>
 __device__ __forceinline__ void ld_multi_f32(const float (&cnt)[W], const F32Const &k, const F32Row (&r)[W],
                                              const F32Col (&c)[W], Cell (&out)[W], float &wmax, float &ymin)
 {
     float p[W], e[W], dn[W], t[W], yr[W], x[W], y[W], yd[W], ar[W], ad[W], kr[W], kd[W], fr_[W], fd[W];
     __builtin_amdgcn_sched_barrier(0);
     LDX_STAGE(p[t_] = r[t_].a * c[t_].a)
-    LDX_STAGE(e[t_] = __builtin_fmaf(r[t_].a, c[t_].a, -p[t_]); dn[t_] = __builtin_fmaf(cnt[t_], k.n, -p[t_]))
-    LDX_STAGE(dn[t_] = dn[t_] - e[t_])                                              // Dn, exact below 2^24
+    if constexpr (kSmallN) {
+        LDX_STAGE(dn[t_] = __builtin_fmaf(cnt[t_], k.n, -p[t_]))                    // Dn, exact: p is
+    } else {
+        LDX_STAGE(e[t_] = __builtin_fmaf(r[t_].a, c[t_].a, -p[t_]); dn[t_] = __builtin_fmaf(cnt[t_], k.n, -p[t_]))
+        LDX_STAGE(dn[t_] = dn[t_] - e[t_])                                          // Dn, exact below 2^24
+    }
     LDX_STAGE(t[t_] = dn[t_] * r[t_].s; const bool neg = dn[t_] < 0.0f;
               x[t_] = neg ? c[t_].ra : c[t_].rr; y[t_] = neg ? c[t_].rr : c[t_].ra)
     LDX_STAGE(t[t_] = t[t_] * c[t_].s; x[t_] = r[t_].ra_s * x[t_]; y[t_] = r[t_].rr_s * y[t_])

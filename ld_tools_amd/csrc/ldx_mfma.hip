@@ -850,6 +850,8 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                     const v4f v = *reinterpret_cast<const v4f *>(ct + 32u * tt * 4u);
                     cols[tt] = F32Col{v.x, v.y, v.z, v.w};
                 }
+                // the sixteen steps, in two instantiations: n <= 4096 needs no error term for the product a1 a2 (ldx_common.h)
+                auto steps = [&](auto small_c) -> bool {
 #pragma unroll 1
                 for (int e = 0; e < 16; ++e) {
                     F32Row rows[MM];
@@ -870,7 +872,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                             c4[tt] = acc[g][tt][e];
                             r4[tt] = rows[g];
                         }
-                        ld_multi_f32<4, Cell>(c4, fc32, r4, cols, o4, wmax, ymin);
+                        ld_multi_f32<4, Cell, decltype(small_c)::value>(c4, fc32, r4, cols, o4, wmax, ymin);
 #pragma unroll
                         for (int tt = 0; tt < 4; ++tt) cell[g * 4 + tt] = o4[tt];
                     }
@@ -906,6 +908,9 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                         qn += np;
                     }
                 }
+                    return true;
+                };
+                if (!(f32_small_n((double)fc32.n) ? steps(std::true_type{}) : steps(std::false_type{}))) return false;
                 // ---- the parked steps: fp64 tier ----
                 LDX_COUNT(0, 1);
                 LDX_COUNT(1, qn);

@@ -205,7 +205,8 @@ __device__ inline Cell all_tiers(double n, double rn, uint32_t c11, double fa1, 
             const F32Col c32[1] = {f32_col(fc_[0].a, fc_[0].ra, fc_[0].rr)};
             Cell h_[1];
             float wmax = 0.0f, ymin = 1.0f;
-            ld_multi_f32<1, Cell>(cnt_, f32k, r32, c32, h_, wmax, ymin);
+            if (f32_small_n(n)) ld_multi_f32<1, Cell, true>(cnt_, f32k, r32, c32, h_, wmax, ymin);   // the variant the kernel picks for this n
+            else ld_multi_f32<1, Cell, false>(cnt_, f32k, r32, c32, h_, wmax, ymin);
             f32_sure = (wmax < f32k.tol) & (ymin > 0.0f);
             if (f32_sure) same = same && same_cell(h_[0], res);
         }
