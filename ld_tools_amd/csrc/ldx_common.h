@@ -359,7 +359,7 @@ __device__ __forceinline__ void ld_multi_fast2(const T (&cnt_scaled)[W], const F
 }
 
 // ---- fp32 first tier (the FP4 matrix kernel's epilogue for units of ordinary SNPs) ------------------------------------
-// The same two quantities, y_r = 10^4 r^2 and y_d = 10^4 D', in float32 from the exact integer Dn -- 25 single-rate
+// The same two quantities, y_r = 10^4 r^2 and y_d = 10^4 D', in float32 from the exact integer Dn -- 24 single-rate
 // VALU instructions per pair instead of ~33 double-rate ones, short enough dependent chains to interleave four pairs
 // -- with a margin test that is wide enough for float32: a lane whose 8 pairs of a step are not ALL provably rounded
 // like the reference hands that step to the fp64 tier above (ld_multi_fast2), through a per-wave queue in LDS, so
