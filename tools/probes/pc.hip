@@ -109,45 +109,75 @@ __device__ __forceinline__ uint32_t lds_addr(const void *p) { return (uint32_t)(
 
 // Roles: waves 0-3 producers (P), waves 4 .. 4+NL-1 loaders (L), the rest epilogue waves (E).
 // Ring slot (one K-block of 256 haplotypes): [A raw bits: 4 P x 2 halves x UROWS x 16 B][B image: 4 steps x 2 halves x ROWS x 16 B][B raw: 2 x ROWS x 16 B]
-template <int MA, int NB, int WPS, int NL, int RING, int S, int D, int PV = 0, int UNR = 1>
+template <int MA, int NB, int WPS, int NL, int RING, int S, int D, int PV = 0, int UNR = 1, int NPC = 1, bool AREG = false>
 __global__ void __launch_bounds__(256 * WPS, WPS)
 pc_kernel(const uint4 *__restrict__ alt, size_t alt_n, uint32_t nchunks, uint32_t n_rows, uint4 *__restrict__ out, size_t out_n, uint32_t npass,
           Stats *__restrict__ stats, F32Const fc, int epi_scale, int mode)
 {
     constexpr uint32_t ROWS = NB * 32u, UROWS = MA * 32u;
-    constexpr uint32_t ARAW = 4u * 2u * UROWS * 16u, IMG = 4u * 2u * ROWS * 16u, BRAW = 2u * ROWS * 16u, SLOT = ARAW + IMG + BRAW;
+    constexpr uint32_t NP = 4u * NPC, IMGROWS = NPC * ROWS;   // producers: 4 row groups x NPC column groups (NPC = 2: two per SIMD)
+    // AREG: the producers load their own A bits (global -> registers, three blocks deep); the ring then holds the image only
+    constexpr uint32_t ARAW = AREG ? 0u : 4u * 2u * UROWS * 16u, IMG = 4u * 2u * IMGROWS * 16u, SLOT = ARAW + IMG;
     constexpr uint32_t HO = UROWS * ROWS * 2u;
     constexpr uint32_t LPR = ROWS / 4u, RPS = 64u / LPR;
     constexpr uint32_t STRIP = 16u, NSTRIP = UROWS / STRIP, STEPS = STRIP / RPS;
-    constexpr uint32_t AITEMS = 4u * UROWS * 2u, ADMA = AITEMS / 64u / NL, BITEMS = ROWS * 2u, BPARTS = BITEMS / 64u;
-    static_assert(AITEMS % (64u * NL) == 0 && BPARTS <= (uint32_t)NL, "whole wave-loads per loader");
+    constexpr uint32_t AITEMS = 4u * UROWS * 2u, ADMA = AREG ? 0u : AITEMS / 64u / NL, ADMA1 = ADMA ? ADMA : 1u, BITEMS = IMGROWS * 2u, BPARTS = BITEMS / 64u;
+    constexpr uint32_t BPL = BPARTS >= (uint32_t)NL ? BPARTS / NL : 1u;   // B wave-loads (and expansions) per loader that has B duty
+    static_assert(AITEMS % (64u * NL) == 0 && BPARTS % BPL == 0, "whole wave-loads per loader");
+    static_assert(!AREG || UNR == 3, "the A ring is three blocks deep");
     static_assert(D <= RING - 2, "loader lead: a producer asks for block q + 1 before it releases block q");
     extern __shared__ uint4 lds[];
     unsigned char *ring = reinterpret_cast<unsigned char *>(lds);
     unsigned char *ho = ring + RING * SLOT;
-    float *ctab = reinterpret_cast<float *>(ho + 4u * S * HO);     // [ROWS][4]
-    float *rtab = ctab + ROWS * 4u;                                // [4][S][UROWS][4]
-    uint32_t *flag = reinterpret_cast<uint32_t *>(rtab + 4u * S * UROWS * 4u);
-    uint32_t *ready = flag, *free_ = flag + RING, *pub = flag + 2 * RING, *claim = pub + 4, *ho_done = claim + 4;   // [4 * S]
+    float *ctab = reinterpret_cast<float *>(ho + NP * S * HO);     // [IMGROWS][4]
+    float *rtab = ctab + IMGROWS * 4u;                             // [NP][S][UROWS][4]
+    uint32_t *flag = reinterpret_cast<uint32_t *>(rtab + NP * S * UROWS * 4u);
+    uint32_t *ready = flag, *free_ = flag + RING, *pub = flag + 2 * RING, *claim = pub + NP, *ho_done = claim + NP;   // [NP * S]
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, l32 = lane & 31u, half = lane >> 5;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t nblocks = nchunks / 2u, total = npass * nblocks;
-    for (uint32_t k = tid; k < 2u * RING + 8u + 4u * S; k += blockDim.x) flag[k] = 0u;
-    for (uint32_t k = tid; k < ROWS; k += blockDim.x)
+    for (uint32_t k = tid; k < 2u * RING + 2u * NP + NP * S; k += blockDim.x) flag[k] = 0u;
+    for (uint32_t k = tid; k < IMGROWS; k += blockDim.x)
         *reinterpret_cast<v4f *>(ctab + k * 4u) = v4f{2000.0f + k, 1.0f / (2000.0f + k), 1.0f / (3008.0f - k), 10.0f / sqrtf((2000.0f + k) * (3008.0f - k))};
     block_sync();
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
     unsigned long long spin_img = 0, spin_ho = 0, n_tasks = 0, n_idle = 0, n_imgs = 0, t_k = 0, t_ho = 0;
-    auto unit_row0 = [&](uint32_t unit, uint32_t p) { return (((blockIdx.x * npass + unit) * 4u + p) * UROWS) % n_rows; };
+    auto unit_row0 = [&](uint32_t unit, uint32_t rgx) { return (((blockIdx.x * npass + unit) * 4u + rgx) * UROWS) % n_rows; };
 
-    if (wave < 4u) {
+    if (wave < NP) {
         // ------------------------------------------------------------------ producer --------------------------------
-        __builtin_amdgcn_s_setprio(3);
-        const uint32_t p = wave;
+        if (!(mode & 16)) __builtin_amdgcn_s_setprio(2);
+        const uint32_t p = wave, rg = p & 3u, cg = p >> 2;
         v16f acc[MA][NB];
         v4u aw[MA], awn[MA];
+        v4u ar[3][MA];   // AREG: ring slot k holds the A words of the blocks q with q % 3 == k
         v4i af0[MA], af1[MA], bf0[NB], bf1[NB];
+        size_t pa_base[MA];
+        uint32_t lu = 0, lc = 0;   // AREG: load cursor (unit, block)
+        auto pa_bases = [&]() {
+#pragma unroll
+            for (int m = 0; m < MA; ++m) {
+                const uint32_t row0 = unit_row0(lu, rg) + 32u * m;
+                pa_base[m] = ((size_t)(row0 / kSlab) * nchunks + half) * kSlab + (row0 % kSlab) + l32;
+                if (pa_base[m] + (size_t)(nblocks - 1u) * 2u * kSlab >= alt_n) { atomicAdd(&g_oob[0], 1ull); pa_base[m] = 0; }
+            }
+        };
+        auto issue_a = [&](v4u (&r)[MA]) {
+            const size_t off = (size_t)lc * (2u * kSlab);
+#pragma unroll
+            for (int m = 0; m < MA; ++m) {
+                const uint4 *pp = alt + pa_base[m] + off;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r[m]) : "v"(pp));
+            }
+            if (lu + 1u < npass || lc + 1u < nblocks) {
+                if (++lc == nblocks) { lc = 0; ++lu; pa_bases(); }
+            }
+        };
+        auto touch = [&](v4u (&r)[MA]) {
+#pragma unroll
+            for (int m = 0; m < MA; ++m) asm volatile("" : "+v"(r[m]));
+        };
         if constexpr ((PV & 6) != 0) {
 #pragma unroll
             for (int m = 0; m < MA; ++m) { aw[m] = v4u{lane, 1u, 2u, 3u}; awn[m] = aw[m]; }
@@ -158,14 +188,14 @@ pc_kernel(const uint4 *__restrict__ alt, size_t alt_n, uint32_t nchunks, uint32_
 #pragma unroll
             for (int tt = 0; tt < NB; ++tt) {
                 if constexpr (PV & 2) asm volatile("" : "+v"(bf[tt]));
-                else bf[tt] = *reinterpret_cast<const v4i *>(buf + (((uint32_t)w * 2u + half) * ROWS + 32u * tt + l32) * 16u);
+                else bf[tt] = *reinterpret_cast<const v4i *>(buf + (((uint32_t)w * 2u + half) * IMGROWS + cg * ROWS + 32u * tt + l32) * 16u);
             }
         };
         auto read_a = [&](v4u (&a)[MA], const unsigned char *slot) {
 #pragma unroll
             for (int m = 0; m < MA; ++m) {
                 if constexpr (PV & 4) asm volatile("" : "+v"(a[m]));
-                else a[m] = *reinterpret_cast<const v4u *>(slot + ((p * 2u + half) * UROWS + 32u * m + l32) * 16u);
+                else a[m] = *reinterpret_cast<const v4u *>(slot + ((rg * 2u + half) * UROWS + 32u * m + l32) * 16u);
             }
         };
         auto expand_a = [&](uint32_t x) {
@@ -190,11 +220,19 @@ pc_kernel(const uint4 *__restrict__ alt, size_t alt_n, uint32_t nchunks, uint32_
                 __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
             }
         };
+        if constexpr (AREG) {
+            pa_bases();
+            issue_a(ar[0]);
+            issue_a(ar[1]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            touch(ar[0]);
+            touch(ar[1]);
+        }
         if (!(mode & 1)) spin_img += wait_ge(&ready[0], NL);
-        read_a(aw, ring);
+        if constexpr (!AREG) read_a(aw, ring);
         read_bf(bf0, ring + ARAW, 0);
 #pragma unroll
-        for (int m = 0; m < MA; ++m) af0[m] = expand_a(aw[m].x);
+        for (int m = 0; m < MA; ++m) af0[m] = expand_a(AREG ? ar[0][m].x : aw[m].x);
         uint32_t u = 0, c = 0, islot = 0, igen = 0;
         unsigned long long tk0 = __builtin_amdgcn_s_memtime();
         auto init_acc = [&]() {
@@ -206,153 +244,206 @@ pc_kernel(const uint4 *__restrict__ alt, size_t alt_n, uint32_t nchunks, uint32_
                     for (int e = 0; e < 16; ++e) acc[m][tt][e] = kMagic;
         };
         init_acc();
-        auto block = [&](uint32_t q) __attribute__((always_inline)) {
-            const unsigned char *sl = ring + islot * SLOT, *rd = sl + ARAW;
-            const uint32_t nslot = islot + 1u == (uint32_t)RING ? 0u : islot + 1u, ngen = nslot == 0u ? igen + 1u : igen;
-            const unsigned char *nsl = ring + nslot * SLOT;
-            read_bf(bf1, rd, 1);
-#pragma unroll
-            for (int m = 0; m < MA; ++m) af1[m] = expand_a(aw[m].y);
-            mma(af0, bf0);
-            interleave(std::integral_constant<int, NB>{});
-            __builtin_amdgcn_sched_barrier(0);
-            read_bf(bf0, rd, 2);
-#pragma unroll
-            for (int m = 0; m < MA; ++m) af0[m] = expand_a(aw[m].z);
-            mma(af1, bf1);
-            interleave(std::integral_constant<int, NB>{});
-            __builtin_amdgcn_sched_barrier(0);
-            if (q + 1u < total && !(mode & 1)) spin_img += wait_ge(&ready[nslot], NL * (ngen + 1u));   // the next block, two steps ahead of its first use
-            read_a(awn, nsl);
-            read_bf(bf1, rd, 3);
-#pragma unroll
-            for (int m = 0; m < MA; ++m) af1[m] = expand_a(aw[m].w);
-            mma(af0, bf0);
-            interleave(std::integral_constant<int, NB + MA>{});
-            __builtin_amdgcn_sched_barrier(0);
-            read_bf(bf0, nsl + ARAW, 0);
-#pragma unroll
-            for (int m = 0; m < MA; ++m) af0[m] = expand_a(awn[m].x);
-            mma(af1, bf1);
-            interleave(std::integral_constant<int, NB>{});
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int m = 0; m < MA; ++m) aw[m] = awn[m];
-            if (!(PV & 8) && lane == 0) __hip_atomic_fetch_add((lds_u32 *)&free_[islot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            islot = nslot;
-            igen = ngen;
-            if (__builtin_expect(++c == nblocks, 0)) {   // hand the unit's counts to the epilogue waves
-                c = 0;
-                const unsigned long long h0 = __builtin_amdgcn_s_memtime();
-                t_k += h0 - tk0;
-                const uint32_t slot = u % S;
-                if (!(mode & 2)) spin_ho += wait_ge(&ho_done[p * S + slot], NSTRIP * (u / S));
-                unsigned char *hb = ho + (p * S + slot) * HO;
-                if (!(mode & 8))
-#pragma unroll
-                for (int m = 0; m < MA; ++m)
-#pragma unroll
-                    for (int tt = 0; tt < NB; ++tt)
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            const uint32_t row = 32u * m + (e & 3) + 8u * (e >> 2) + 4u * half, col = 32u * tt + l32;
-                            *reinterpret_cast<uint16_t *>(hb + (row * ROWS + col) * 2u) = (uint16_t)__float_as_uint(acc[m][tt][e]);
-                        }
-                for (uint32_t r = lane; r < UROWS; r += 64u) {
-                    const float a = 1500.0f + (float)r;
-                    *reinterpret_cast<v4f *>(rtab + ((p * S + slot) * UROWS + r) * 4u) = v4f{a, 6.5f, 2.9f, 0.0045f};
-                }
-                lds_signal_add(&pub[p], NSTRIP, lane);
-                ++u;
-                init_acc();
-                tk0 = __builtin_amdgcn_s_memtime();
-                t_ho += tk0 - h0;
-            }
-        };
+#define PC_BLOCK(q, CURV)                                                                                        \
+        {                                                                                                         \
+            constexpr int CUR = (CURV) % 3, NXT = (CUR + 1) % 3, PRV = (CUR + 2) % 3; \
+            if constexpr (AREG) issue_a(ar[PRV]); \
+            const unsigned char *sl = ring + islot * SLOT, *rd = sl + ARAW; \
+            const uint32_t nslot = islot + 1u == (uint32_t)RING ? 0u : islot + 1u, ngen = nslot == 0u ? igen + 1u : igen; \
+            const unsigned char *nsl = ring + nslot * SLOT; \
+            const uint32_t early = *(const volatile lds_u32 *)&ready[nslot];   /* the next block's flag, read two steps before it is needed */ \
+            read_bf(bf1, rd, 1); \
+_Pragma("unroll") \
+            for (int m = 0; m < MA; ++m) af1[m] = expand_a(AREG ? ar[CUR][m].y : aw[m].y); \
+            mma(af0, bf0); \
+            interleave(std::integral_constant<int, NB>{}); \
+            __builtin_amdgcn_sched_barrier(0); \
+            read_bf(bf0, rd, 2); \
+_Pragma("unroll") \
+            for (int m = 0; m < MA; ++m) af0[m] = expand_a(AREG ? ar[CUR][m].z : aw[m].z); \
+            mma(af1, bf1); \
+            interleave(std::integral_constant<int, NB>{}); \
+            __builtin_amdgcn_sched_barrier(0); \
+            if (q + 1u < total && !(mode & 1) && \
+                __builtin_expect((int)(__builtin_amdgcn_readfirstlane(early) - NL * (ngen + 1u)) < 0, 0)) \
+                spin_img += 1u + wait_ge(&ready[nslot], NL * (ngen + 1u)); \
+            if constexpr (!AREG) read_a(awn, nsl); \
+            read_bf(bf1, rd, 3); \
+_Pragma("unroll") \
+            for (int m = 0; m < MA; ++m) af1[m] = expand_a(AREG ? ar[CUR][m].w : aw[m].w); \
+            mma(af0, bf0); \
+            interleave(std::integral_constant<int, AREG ? NB : NB + MA>{}); \
+            __builtin_amdgcn_sched_barrier(0); \
+            if constexpr (AREG) { \
+                asm volatile("s_waitcnt vmcnt(%0)" : : "n"(MA) : "memory"); \
+                touch(ar[NXT]); \
+            } \
+            read_bf(bf0, nsl + ARAW, 0); \
+_Pragma("unroll") \
+            for (int m = 0; m < MA; ++m) af0[m] = expand_a(AREG ? ar[NXT][m].x : awn[m].x); \
+            mma(af1, bf1); \
+            interleave(std::integral_constant<int, NB>{}); \
+            __builtin_amdgcn_sched_barrier(0); \
+            if constexpr (!AREG) { \
+_Pragma("unroll") \
+                for (int m = 0; m < MA; ++m) aw[m] = awn[m]; \
+            } \
+            if (!(PV & 8) && lane == 0) __hip_atomic_fetch_add((lds_u32 *)&free_[islot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+            islot = nslot; \
+            igen = ngen; \
+            if (__builtin_expect(++c == nblocks, 0)) { \
+                c = 0; \
+                const unsigned long long h0 = __builtin_amdgcn_s_memtime(); \
+                t_k += h0 - tk0; \
+                const uint32_t slot = u % S; \
+                if (!(mode & 2)) spin_ho += wait_ge(&ho_done[p * S + slot], NSTRIP * (u / S)); \
+                unsigned char *hb = ho + (p * S + slot) * HO; \
+                if (!(mode & 8)) \
+_Pragma("unroll") \
+                for (int m = 0; m < MA; ++m) \
+_Pragma("unroll") \
+                    for (int tt = 0; tt < NB; ++tt) \
+_Pragma("unroll") \
+                        for (int e = 0; e < 16; ++e) { \
+                            const uint32_t row = 32u * m + (e & 3) + 8u * (e >> 2) + 4u * half, col = 32u * tt + l32; \
+                            *reinterpret_cast<uint16_t *>(hb + (row * ROWS + col) * 2u) = (uint16_t)__float_as_uint(acc[m][tt][e]); \
+                        } \
+                for (uint32_t r = lane; r < UROWS; r += 64u) { \
+                    const float a = 1500.0f + (float)r; \
+                    *reinterpret_cast<v4f *>(rtab + ((p * S + slot) * UROWS + r) * 4u) = v4f{a, 6.5f, 2.9f, 0.0045f}; \
+                } \
+                lds_signal_add(&pub[p], NSTRIP, lane); \
+                ++u; \
+                init_acc(); \
+                tk0 = __builtin_amdgcn_s_memtime(); \
+                t_ho += tk0 - h0; \
+            } \
+        }
 #pragma unroll 1
         for (uint32_t q = 0; q < total; q += UNR) {   // total is a multiple of UNR (host)
-#pragma unroll
-            for (int k = 0; k < UNR; ++k) block(q + k);
+            PC_BLOCK(q, 0)
+            if constexpr (UNR > 1) PC_BLOCK(q + 1, 1)
+            if constexpr (UNR > 2) PC_BLOCK(q + 2, 2)
+            if constexpr (UNR > 3) PC_BLOCK(q + 3, 3)
         }
-    } else if (wave < 4u + NL) {
+        if constexpr (AREG) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            touch(ar[0]);
+            touch(ar[1]);
+            touch(ar[2]);
+        }
+    } else if (wave < NP + NL) {
         // ------------------------------------------------------------------ loader ----------------------------------
-        // Per block and loader: ADMA wave-loads of A bits (all loaders) and, for loaders w < BPARTS, one wave-load of B bits
-        // plus the expansion of those 64 items into the image, D blocks behind the loads.
-        __builtin_amdgcn_s_setprio(2);
-        const uint32_t w = wave - 4u;
-        const uint32_t ring_base = lds_addr(ring);
-        const bool b_duty = w < BPARTS;
-        const uint32_t bitem = w * 64u + lane, bhalf = bitem / ROWS, brow = bitem % ROWS;
-        size_t abase[ADMA], bbase = 0;   // this lane's source index (uint4 units) at block 0 of the current unit
-        uint32_t unit = 0, cc = 0;
+        // Per block and loader: ADMA wave-items of A bits (global -> registers -> LDS as they are) and BPL wave-items of B bits
+        // (global -> registers -> expanded -> image).  The loads run two blocks ahead in REGISTERS, whatever the state of
+        // the ring: only the LDS writes wait for a free slot, so the ring hand-shake sees LDS latency, not memory latency.
+        // Plain C++ loads in a loop unrolled by two with static names: hipcc counts them itself.
+        if (!(mode & 16)) __builtin_amdgcn_s_setprio(3);
+        const uint32_t w = wave - NP;
+        const bool b_duty = w * BPL < BPARTS;
+        size_t abase[ADMA1], bbase[BPL];
+        uint32_t lunit = 0, lcc = 0;   // load cursor
         auto unit_bases = [&]() {
 #pragma unroll
             for (uint32_t k = 0; k < ADMA; ++k) {
                 const uint32_t a = (w * ADMA + k) * 64u + lane;
-                const uint32_t pp = a / (UROWS * 2u), rem = a % (UROWS * 2u), hf = rem / UROWS, row = unit_row0(unit, pp) + rem % UROWS;
+                const uint32_t pp = a / (UROWS * 2u), rem = a % (UROWS * 2u), hf = rem / UROWS, row = unit_row0(lunit, pp) + rem % UROWS;
                 abase[k] = ((size_t)(row / kSlab) * nchunks + hf) * kSlab + (row % kSlab);
                 if (abase[k] + (size_t)(nblocks - 1u) * 2u * kSlab >= alt_n) { atomicAdd(&g_oob[0], 1ull); abase[k] = 0; }
             }
-            const uint32_t jrow = ((blockIdx.x * 7u + unit) * ROWS) % n_rows + brow;
-            bbase = ((size_t)(jrow / kSlab) * nchunks + bhalf) * kSlab + (jrow % kSlab);
-            if (bbase + (size_t)(nblocks - 1u) * 2u * kSlab >= alt_n) { atomicAdd(&g_oob[0], 1ull); bbase = 0; }
+#pragma unroll
+            for (uint32_t k = 0; k < BPL; ++k) {
+                const uint32_t bitem = (w * BPL + k) * 64u + lane, bhalf = (bitem / IMGROWS) & 1u, brow = bitem % IMGROWS;
+                const uint32_t jrow = ((blockIdx.x * 7u + lunit) * IMGROWS) % n_rows + brow;
+                bbase[k] = ((size_t)(jrow / kSlab) * nchunks + bhalf) * kSlab + (jrow % kSlab);
+                if (bbase[k] + (size_t)(nblocks - 1u) * 2u * kSlab >= alt_n) { if (b_duty) atomicAdd(&g_oob[0], 1ull); bbase[k] = 0; }
+            }
         };
         unit_bases();
-        auto dma = [&](uint32_t lds_dst, size_t idx) {
-            const uint4 *gsrc = alt + idx;
-            unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+        // The loads are asm statements with static register homes (r0 / r1, loop unrolled by two) and hand-counted
+        // s_waitcnt vmcnt: left to hipcc, the same loop copies the loaded registers at the back edge and waits for every
+        // load right behind its issue (a full memory latency per block).  A loader issues nothing else that vmcnt counts.
+        auto gl = [&](v4u &dst, size_t idx) {
+            const uint4 *p = alt + idx;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p));
         };
+        uint32_t islot = 0, igen = 0;
         auto body = [&](auto bd) {
             constexpr bool kB = decltype(bd)::value;
-            constexpr uint32_t NDMA = ADMA + (kB ? 1u : 0u);
-            uint32_t islot = 0, igen = 0, dslot = 0;
-#pragma unroll 1
-            for (uint32_t i = 0; i < total + D; ++i) {
-                if (i < total) {
-                    const unsigned long long f0 = __builtin_amdgcn_s_memtime();
-                    n_idle += wait_ge(&free_[islot], 4u * igen);
-                    spin_img += __builtin_amdgcn_s_memtime() - f0;   // cycles waiting for a free slot
-                    const uint32_t sbase = ring_base + islot * SLOT;
-                    const size_t off = (size_t)cc * (2u * kSlab);
+            constexpr uint32_t NLOAD = ADMA + (kB ? BPL : 0u);
+            v4u a0[ADMA1], a1[ADMA1], b0[BPL], b1[BPL];
+            auto load = [&](v4u (&ra)[ADMA1], v4u (&rb)[BPL]) {   // the block at the load cursor (past the end: the last block again)
+                const size_t off = (size_t)lcc * (2u * kSlab);
 #pragma unroll
-                    for (uint32_t k = 0; k < ADMA; ++k) dma(sbase + (w * ADMA + k) * 1024u, abase[k] + off);
-                    if (kB) dma(sbase + ARAW + IMG + w * 1024u, bbase + off);
-                    if (++islot == (uint32_t)RING) { islot = 0; ++igen; }
-                    if (++cc == nblocks) { cc = 0; ++unit; if (unit < npass) unit_bases(); }
+                for (uint32_t k = 0; k < ADMA; ++k) gl(ra[k], abase[k] + off);
+                if (kB) {
+#pragma unroll
+                    for (uint32_t k = 0; k < BPL; ++k) gl(rb[k], bbase[k] + off);
                 }
-                if (i >= (uint32_t)D) {
-                    const unsigned long long v0 = __builtin_amdgcn_s_memtime();
-                    if (i < total) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NDMA * D) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    const unsigned long long v1 = __builtin_amdgcn_s_memtime();
-                    spin_ho += v1 - v0;   // cycles waiting for its DMAs
-                    unsigned char *sl = ring + dslot * SLOT;
-                    if (kB) {
-                        const v4u raw = *reinterpret_cast<const v4u *>(sl + ARAW + IMG + bitem * 16u);
+                if (lunit + 1u < npass || lcc + 1u < nblocks) {
+                    if (++lcc == nblocks) { lcc = 0; ++lunit; unit_bases(); }
+                }
+            };
+            auto store = [&](v4u (&ra)[ADMA1], v4u (&rb)[BPL]) {
+                const unsigned long long f0 = __builtin_amdgcn_s_memtime();
+                n_idle += wait_ge(&free_[islot], NP * igen);
+                const unsigned long long f1 = __builtin_amdgcn_s_memtime();
+                spin_img += f1 - f0;   // cycles waiting for a free slot
+                asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NLOAD) : "memory");   // all but the other register set's loads
+#pragma unroll
+                for (uint32_t k = 0; k < ADMA; ++k) asm volatile("" : "+v"(ra[k]));
+                if (kB) {
+#pragma unroll
+                    for (uint32_t k = 0; k < BPL; ++k) asm volatile("" : "+v"(rb[k]));
+                }
+                const unsigned long long f2 = __builtin_amdgcn_s_memtime();
+                spin_ho += f2 - f1;   // cycles waiting for the loads
+                unsigned char *sl = ring + islot * SLOT;
+#pragma unroll
+                for (uint32_t k = 0; k < ADMA; ++k) *reinterpret_cast<v4u *>(sl + ((w * ADMA + k) * 64u + lane) * 16u) = ra[k];
+                if (kB) {
+#pragma unroll
+                    for (uint32_t k = 0; k < BPL; ++k) {
+                        const uint32_t bitem = (w * BPL + k) * 64u + lane, bhalf = bitem / IMGROWS, brow = bitem % IMGROWS;
 #pragma unroll
                         for (int s4 = 0; s4 < 4; ++s4)
-                            *reinterpret_cast<v4i *>(sl + ARAW + (((uint32_t)s4 * 2u + bhalf) * ROWS + brow) * 16u) = expand32_b4(raw[s4]);
+                            *reinterpret_cast<v4i *>(sl + ARAW + (((uint32_t)s4 * 2u + bhalf) * IMGROWS + brow) * 16u) = expand32_b4(rb[k][s4]);
                     }
-                    lds_signal_add(&ready[dslot], 1u, lane);
-                    if (++dslot == (uint32_t)RING) dslot = 0;
-                    t_k += __builtin_amdgcn_s_memtime() - v1;   // expansion + signal
-                    ++n_imgs;
                 }
+                lds_signal_add(&ready[islot], 1u, lane);
+                if (++islot == (uint32_t)RING) { islot = 0; ++igen; }
+                t_k += __builtin_amdgcn_s_memtime() - f2;   // expansion + LDS writes + signal
+                ++n_imgs;
+            };
+            load(a0, b0);
+            load(a1, b1);
+#pragma unroll 1
+            for (uint32_t i = 0; i < total; i += 2) {   // total is even (host)
+                store(a0, b0);
+                load(a0, b0);
+                store(a1, b1);
+                load(a1, b1);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (uint32_t k = 0; k < ADMA; ++k) asm volatile("" : "+v"(a0[k]), "+v"(a1[k]));
+            if (kB) {
+#pragma unroll
+                for (uint32_t k = 0; k < BPL; ++k) asm volatile("" : "+v"(b0[k]), "+v"(b1[k]));
             }
         };
         if (!(mode & 4)) { if (b_duty) body(std::true_type{}); else body(std::false_type{}); }
     } else {
         // ------------------------------------------------------------------ epilogue wave ---------------------------
-        const uint32_t h = wave - 4u - NL;
+        const uint32_t h = wave - NP - NL;
+        if (mode & 32) __builtin_amdgcn_s_setprio(3);
         const uint32_t strips_per_p = npass * NSTRIP;
-        uint32_t rot = h & 3u, done_p = 0;
+        uint32_t rot = h % NP, done_p = 0;
         const uint32_t col4 = lane % LPR, rsub = lane / LPR;
-        while (done_p != 15u && !(mode & 2)) {
+        while (done_p != (1u << NP) - 1u && !(mode & 2)) {
             uint32_t got = 0xFFFFFFFFu, gp = 0;
-            for (uint32_t k = 0; k < 4u && got == 0xFFFFFFFFu; ++k) {
-                const uint32_t pp = (rot + k) & 3u;
+            for (uint32_t k = 0; k < NP && got == 0xFFFFFFFFu; ++k) {
+                const uint32_t pp = (rot + k) % NP;
                 if (done_p & (1u << pp)) continue;
                 const uint32_t cl = lds_peek(&claim[pp]);
                 if (cl >= strips_per_p) { done_p |= 1u << pp; continue; }
@@ -370,22 +461,28 @@ pc_kernel(const uint4 *__restrict__ alt, size_t alt_n, uint32_t nchunks, uint32_
                 continue;
             }
             asm volatile("" ::: "memory");
-            rot = (gp + 1u) & 3u;
+            rot = (gp + 1u) % NP;
             const uint32_t uu = got / NSTRIP, ss = got % NSTRIP, slot = uu % S;
             const unsigned char *hb = ho + (gp * S + slot) * HO;
             const float *rt = rtab + (gp * S + slot) * UROWS * 4u;
             F32Col cols[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const v4f v = *reinterpret_cast<const v4f *>(ctab + (col4 * 4u + k) * 4u);
+                const v4f v = *reinterpret_cast<const v4f *>(ctab + ((gp >> 2) * ROWS + col4 * 4u + k) * 4u);
                 cols[k] = F32Col{v.x, v.y, v.z, v.w};
             }
-            const uint32_t urow0 = (((blockIdx.x * npass + uu) * 4u + gp) * UROWS);   // output rows of the unit
+            const uint32_t urow0 = (((blockIdx.x * npass + uu) * NP + gp) * UROWS);   // output rows of the unit
+            v2u c2n = *reinterpret_cast<const v2u *>(hb + ((ss * STRIP + rsub) * ROWS + col4 * 4u) * 2u);
+            v4f rvn = *reinterpret_cast<const v4f *>(rt + (ss * STRIP + rsub) * 4u);
 #pragma unroll 1
             for (uint32_t st = 0; st < STEPS; ++st) {
                 const uint32_t row = ss * STRIP + st * RPS + rsub;
-                const v2u c2 = *reinterpret_cast<const v2u *>(hb + (row * ROWS + col4 * 4u) * 2u);
-                const v4f rv = *reinterpret_cast<const v4f *>(rt + row * 4u);
+                const v2u c2 = c2n;
+                const v4f rv = rvn;
+                if (st + 1u < STEPS) {   // the next step's operands: their LDS latency hides behind this step's arithmetic
+                    c2n = *reinterpret_cast<const v2u *>(hb + ((row + RPS) * ROWS + col4 * 4u) * 2u);
+                    rvn = *reinterpret_cast<const v4f *>(rt + (row + RPS) * 4u);
+                }
                 float c4[4] = {(float)(c2.x & 0xFFFFu), (float)(c2.x >> 16), (float)(c2.y & 0xFFFFu), (float)(c2.y >> 16)};
                 F32Row r4[4];
 #pragma unroll
@@ -423,14 +520,15 @@ pc_kernel(const uint4 *__restrict__ alt, size_t alt_n, uint32_t nchunks, uint32_
     }
 }
 
-template <int MA, int NB, int WPS, int NL, int RING, int S, int D, int PV = 0, int UNR = 1>
+template <int MA, int NB, int WPS, int NL, int RING, int S, int D, int PV = 0, int UNR = 1, int NPC = 1, bool AREG = false>
 static void run(const char *name, const uint4 *alt, size_t alt_n, uint32_t nchunks, uint32_t n_rows, uint4 *out, size_t out_n, uint32_t npass, int epi_scale,
                 int mode = 0, int blocks = 256)
 {
     constexpr uint32_t ROWS = NB * 32u, UROWS = MA * 32u;
-    const size_t lds = RING * (4u * 2u * UROWS * 16u + 4u * 2u * ROWS * 16u + 2u * ROWS * 16u) + 4u * S * (UROWS * ROWS * 2u) + ROWS * 16u +
-                       4u * S * UROWS * 16u + (2 * RING + 8 + 4 * S) * 4u;
-    auto kern = pc_kernel<MA, NB, WPS, NL, RING, S, D, PV, UNR>;
+    constexpr uint32_t NP = 4u * NPC, IMGROWS = NPC * ROWS;
+    const size_t lds = RING * ((AREG ? 0u : 4u * 2u * UROWS * 16u) + 4u * 2u * IMGROWS * 16u) + NP * S * (UROWS * ROWS * 2u) + IMGROWS * 16u +
+                       NP * S * UROWS * 16u + (2 * RING + 2 * NP + NP * S) * 4u;
+    auto kern = pc_kernel<MA, NB, WPS, NL, RING, S, D, PV, UNR, NPC, AREG>;
     if (lds > 163840u || hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         printf("%s: cannot set %zu bytes of LDS\n", name, lds);
         return;
@@ -460,17 +558,17 @@ static void run(const char *name, const uint4 *alt, size_t alt_n, uint32_t nchun
     for (int b = 0; b < blocks; ++b)
         for (int w = 0; w < waves; ++w) {
             const Stats &s = h[b * waves + w];
-            if (w < 4) { pc += s.cycles; pk += s.t_k; ph += s.t_ho; psi += s.spin_img; psh += s.spin_ho; }
-            else if (w < 4 + NL) { li += s.idle; lf += s.spin_img; lv += s.spin_ho; le += s.t_k; lc += s.cycles; }
+            if (w < (int)NP) { pc += s.cycles; pk += s.t_k; ph += s.t_ho; psi += s.spin_img; psh += s.spin_ho; }
+            else if (w < (int)NP + NL) { li += s.idle; lf += s.spin_img; lv += s.spin_ho; le += s.t_k; lc += s.cycles; }
             else { et += s.tasks; ei += s.idle; }
         }
-    const double np = blocks * 4.0, ne = blocks * (waves - 4.0 - NL), nl = blocks * (double)NL;
-    const double pairs = (double)blocks * npass * 4.0 * UROWS * ROWS;
+    const double np = blocks * (double)NP, ne = blocks * (waves - (double)NP - NL), nl = blocks * (double)NL;
+    const double pairs = (double)blocks * npass * (double)NP * UROWS * ROWS;
     const double nblocks = nchunks / 2.0, mfma_per_p = npass * nblocks * 4.0 * MA * NB;
     const double hap = nchunks * 128.0;
-    if (mode | PV | (UNR - 1)) printf("[mode %2d PV %2d unroll %d] ", mode, PV, UNR);
+    if (mode | PV | (UNR - 1) | (NPC - 1)) printf("[mode %2d PV %2d unroll %d, %d P/SIMD%s] ", mode, PV, UNR, NPC, AREG ? ", A in regs" : "");
     printf("%-22s vgpr=%3d lds=%6zu %8.3f ms %6.2fe11 pairs/s frac=%.3f | P %7.0f cyc/unit (K %7.0f, hand-off %5.0f), %5.1f cyc/MFMA, "
-           "spins/unit: ring %.1f ho %.1f | L cyc/block %.0f: free-wait %.0f dma-wait %.0f expand %.0f | E %.1f tasks, %.0f idle polls per wave\n",
+           "spins/unit: ring %.1f ho %.1f | L cyc/block %.0f: free-wait %.0f load-wait %.0f write+signal %.0f | E %.1f tasks, %.0f idle polls per wave\n",
            name, fa.numRegs, lds, best, pairs / (best * 1e-3) / 1e11, pairs * 2.0 * hap / (best * 1e-3) / 1e16, pc / np / npass, pk / np / npass,
            ph / np / npass, pc / np / mfma_per_p, psi / np / npass, psh / np / npass, lc / nl / (npass * nblocks), lf / nl / (npass * nblocks), lv / nl / (npass * nblocks), le / nl / (npass * nblocks), et / ne, ei / ne);
     unsigned long long oob[4] = {0, 0, 0, 0};
@@ -492,7 +590,7 @@ int main(int argc, char **argv)
     setvbuf(stdout, nullptr, _IONBF, 0);
     if (hipMalloc(&alt, alt_bytes) != hipSuccess) { printf("hipMalloc failed\n"); return 1; }
     (void)hipMemcpy(alt, host.data(), alt_bytes, hipMemcpyHostToDevice);
-    const size_t out_bytes = (size_t)256 * npass * 4 * 96 * 128 * 4 + (1u << 20);
+    const size_t out_bytes = (size_t)256 * npass * 8 * 96 * 128 * 4 + (1u << 20);
     if (hipMalloc(&out, out_bytes) != hipSuccess) { printf("hipMalloc failed\n"); return 1; }
     const size_t alt_n = alt_bytes / 16, out_n = out_bytes / 16;
     (void)hipMemset(out, 0, out_bytes);
@@ -525,13 +623,12 @@ int main(int argc, char **argv)
     for (int epi = 1; epi >= epi_lo; --epi) {
         int cfg = 0;
         printf("---- epilogue scale %d, %u passes per CU\n", epi, npass);
-        //  MA NB WPS NL RING S  D
-        run<2, 2, 4, 4, 5, 1, 2>("64x64 4w L4 ring5 D2", alt, alt_n, nchunks, n_rows, out, out_n, npass, epi);
-        run<2, 2, 4, 2, 5, 1, 2>("64x64 4w L2 ring5 D2", alt, alt_n, nchunks, n_rows, out, out_n, npass, epi);
-        run<2, 2, 4, 4, 4, 2, 1>("64x64 4w L4 ring4 D1 S2", alt, alt_n, nchunks, n_rows, out, out_n, npass, epi);
-        run<2, 2, 3, 4, 5, 1, 2>("64x64 3w L4 ring5 D2", alt, alt_n, nchunks, n_rows, out, out_n, npass, epi);
-        run<3, 2, 3, 4, 4, 1, 1>("96x64 3w L4 ring4 D1", alt, alt_n, nchunks, n_rows, out, out_n, npass, epi);
-        run<3, 2, 3, 2, 4, 1, 1>("96x64 3w L2 ring4 D1", alt, alt_n, nchunks, n_rows, out, out_n, npass, epi);
+        //  MA NB WPS NL RING S  D  PV UNR NPC AREG
+        run<2, 2, 4, 2, 5, 1, 1, 0, 3, 2, true>("2P+2H 64x64 L2 ring5", alt, alt_n, nchunks, n_rows, out, out_n, npass, epi);
+        run<2, 2, 4, 2, 5, 1, 1, 0, 3, 2, true>("same, no priorities", alt, alt_n, nchunks, n_rows, out, out_n, npass, epi, 16);
+        run<2, 2, 4, 2, 5, 1, 1, 0, 3, 2, true>("same, E prio 3, others 0", alt, alt_n, nchunks, n_rows, out, out_n, npass, epi, 48);
+        run<2, 2, 4, 2, 5, 1, 1, 0, 3, 2, true>("same, E 3, P 2, L 3", alt, alt_n, nchunks, n_rows, out, out_n, npass, epi, 32);
+        run<2, 2, 4, 2, 3, 1, 1, 0, 2, 2, false>("2P+2H A via LDS ring3, no prio", alt, alt_n, nchunks, n_rows, out, out_n, npass, epi, 16);
     }
 #undef run
     return 0;
