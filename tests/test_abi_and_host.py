@@ -136,6 +136,38 @@ def test_device_calls_fail_loudly_without_gpu():
         calc_ld([], [])
 
 
+def test_reference_import_lines_work_unchanged():
+    """the drop-in keeps the reference's MODULE PATH.  The three scripts import the hot path with
+    `from backend.calc_ld import calc_ld` (ld_triangle.py:377, ld_area.py:309, ld_lite.py:61) and the two lookups with
+    `from backend.get_sample_names import get_sample_names` / `from backend.create_src_dict import create_src_dict`
+    (ld_triangle.py:373-374): with the repository root on sys.path those statements run as they stand and bind the GPU
+    implementation (no CPU code behind them: the call raises without a GPU)."""
+    import subprocess
+    import sys
+
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from backend.calc_ld import calc_ld\n"                               # ld_triangle.py:377, verbatim
+        "from backend.get_sample_names import get_sample_names\n"             # ld_triangle.py:373
+        "from backend.create_src_dict import create_src_dict\n"               # ld_triangle.py:374
+        "import ld_tools_amd.backend.calc_ld as impl, inspect\n"
+        "assert calc_ld is impl.calc_ld\n"
+        "assert list(inspect.signature(calc_ld).parameters) == ['var_1_genotypes', 'var_2_genotypes']\n"
+        "import torch\n"
+        "if not torch.cuda.is_available():\n"
+        "    from ld_tools_amd import LdxError\n"
+        "    try:\n"
+        "        calc_ld([1, 0, 1, 0], [1, 1, 0, 0])\n"
+        "    except LdxError:\n"
+        "        print('raises')\n"
+        "else:\n"
+        "    print(calc_ld([1, 0, 1, 0, 1, 1, 0, 0], [1, 0, 1, 0, 0, 1, 0, 1]))\n"
+    ) % str(ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd="/", timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.strip() in ("raises", "{'r_square': 0.25, 'd_prime': 0.5, 'var_1_alt_freq': 0.5, 'var_2_alt_freq': 0.5}")
+
+
 def test_encode_codes_matches_list_count_semantics():
     from ld_tools_amd import encode_codes
 

@@ -952,6 +952,17 @@ def test_calc_ld_dropin(gpu, kat):
     with pytest.raises(ZeroDivisionError):
         calc_ld([], [1])
     assert str(calc_ld(np.array([1, 0, 1, 0]), np.array([1, 1, 0, 0]))) == str(calc_ld([1, 0, 1, 0], [1, 1, 0, 0]))
+    # the reference's own import statement (ld_triangle.py:377), repository root on sys.path: the same function
+    import importlib
+    import sys
+    from pathlib import Path
+    root = str(Path(__file__).resolve().parent.parent)
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    ref_path = importlib.import_module("backend.calc_ld")
+    assert ref_path.calc_ld is calc_ld
+    for item in kat["literal"]:
+        assert str(ref_path.calc_ld(item["g1"], item["g2"])) == str(item["expect"])
 
 
 def test_fuzz_matrix_kernels_against_popcount(gpu):
