@@ -61,6 +61,9 @@ def parse(argv=None):
                     help="result cells: k16 = 4 bytes per pair (two uint16 k = value * 10^4, lossless), ld32 = 8 bytes (two float32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="N = 1: skip the int8 / popcount / other-format legs")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="N = 1: skip BASELINE configs[4] (50 000 x 1008 triangle), configs[2] (100 000-SNP ld_area) and the "
+                         "pack / host-to-device timings that follow the headline")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--force-dist", action="store_true", help="run the sharded path (process group + all-gather) even at world 1")
     ap.add_argument("--cpu-sample-snps", type=int, default=320)
@@ -90,21 +93,47 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
+RC_VERIFY = 97      # a rank's timed steps did not reproduce the triangle: a wrong RESULT, never retried, never hidden
+RC_DEADLINE = 124   # the rank processes overran --deadline
+
+
 def launch_ranks(args, argv) -> int:
     """Start one rank per GPU through torch.distributed.run in a child process and relay rank 0's JSON line.  This
-    process never initialises HIP (an exec or fork after HIP init is what must not happen; a plain child is fine)."""
+    process never initialises HIP (an exec or fork after HIP init is what must not happen; a plain child is fine).
+
+    The child runs in its own session: on a deadline overrun the WHOLE process group (torch.distributed.run and the rank
+    grandchildren that hold the GPUs) is terminated, and nothing is started beside it afterwards.  A failed run is
+    repeated once in the plainest mode (eager launches, exchange not overlapped) -- except after a verification failure
+    (RC_VERIFY) or a deadline overrun, which are returned as they are; the JSON line says whether it is a second attempt."""
+    import signal
+
     def attempt(extra):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(Path(__file__).resolve())] + argv + extra
         env = dict(os.environ)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, env=env, start_new_session=True)
         try:
-            proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=None, text=True, timeout=args.deadline, env=env)
-        except subprocess.TimeoutExpired as exc:
-            print(f"[bench] the rank processes overran the deadline of {args.deadline:.0f} s", file=sys.stderr)
-            out = exc.stdout if isinstance(exc.stdout, str) else (exc.stdout or b"").decode("utf-8", "replace")
-            return 124, out
-        return proc.returncode, proc.stdout or ""
+            out, _ = proc.communicate(timeout=args.deadline)
+            return proc.returncode, out or ""
+        except subprocess.TimeoutExpired:
+            print(f"[bench] the rank processes overran the deadline of {args.deadline:.0f} s: ending their process group",
+                  file=sys.stderr)
+            for sig, grace in ((signal.SIGTERM, 15.0), (signal.SIGKILL, 15.0)):
+                try:
+                    os.killpg(proc.pid, sig)        # the session leader's pid is the group id
+                except ProcessLookupError:
+                    break
+                try:
+                    proc.wait(timeout=grace)
+                    break
+                except subprocess.TimeoutExpired:
+                    continue
+            try:
+                out, _ = proc.communicate(timeout=5.0)
+            except Exception:                       # noqa: BLE001
+                out = ""
+            return RC_DEADLINE, out or ""
 
     def json_line(text):
         for line in reversed(text.splitlines()):
@@ -114,14 +143,31 @@ def launch_ranks(args, argv) -> int:
 
     rc, out = attempt([])
     line = json_line(out)
+    first_rc, retried = rc, False
+    if rc == RC_VERIFY:
+        print("[bench] a rank's timed steps did not reproduce the triangle: NOT retried", file=sys.stderr)
+        sys.stdout.write(out)
+        return RC_VERIFY
+    if rc == RC_DEADLINE:
+        sys.stdout.write(out)
+        return RC_DEADLINE
     if (rc != 0 or line is None) and not (args.no_graph and args.no_overlap):
         print(f"[bench] rank processes failed (rc {rc}); once more in the plainest mode: eager launches, exchange not "
               "overlapped", file=sys.stderr)
+        retried = True
         rc, out = attempt(["--no-graph", "--no-overlap"])
         line = json_line(out)
     if line is None:
         sys.stdout.write(out)
         return rc or 1
+    try:        # the record says how it came about
+        rec = json.loads(line)
+        rec["retried"] = retried
+        rec["first_attempt_rc"] = first_rc
+        rec["first_attempt_mode"] = "as requested" if not retried else "as requested (failed); this line: --no-graph --no-overlap"
+        line = json.dumps(rec)
+    except ValueError:
+        pass
     print(line, flush=True)
     return rc
 
@@ -183,6 +229,120 @@ def _cpu_model():
     except OSError:
         pass
     return "unknown"
+
+
+# ------------------------------------------------------------------------------------------ other workloads (N = 1)
+def other_workloads(torch, dev, fmt, bench_codes):
+    """BASELINE.json configs[4] and configs[2] on the driver-run line, each a few launches at settled clocks and each
+    checked against a second, independently computed result; plus what SURVEY 8d asks to report beside pairs/s: the pack
+    kernel and the host-to-device copy of the bench panel's codes (never part of `value`)."""
+    from ld_tools_amd import PackedPanel, ld_area, ld_triangle, ops, synth
+    from ld_tools_amd._lib import lib
+
+    def events():
+        return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    res = {}
+    # ---- configs[4]: ld_triangle 50 000 x 1008 (EUR sub-panel), the HBM-write regime ----
+    try:
+        n, h = 50000, 1008
+        p = PackedPanel.from_codes(synth.synth_codes_device(n, h, seed=synth.BENCH_SEED, device=dev))
+        o = ld_triangle(p, fmt=fmt)
+        for _ in range(3):
+            ld_triangle(p, out=o, fmt=fmt)
+        torch.cuda.synchronize()
+        o.cells.fill_(-1)
+        reps = 8
+        a, c = events()
+        a.record()
+        for _ in range(reps):
+            ld_triangle(p, out=o, fmt=fmt)
+        c.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(c) / reps
+        chk = ld_triangle(p, fmt=fmt, path="popcount")          # the independent kernel (AND + popcount, fp64 epilogue)
+        torch.cuda.synchronize()
+        same = bool(torch.equal(chk.cells.view(torch.int32), o.cells.view(torch.int32)))
+        del chk
+        pairs = n * (n - 1) // 2
+        cell_bytes = 4 if fmt == "k16" else 8
+        alg = float(cell_bytes) * pairs + lib.ldx_plane_bytes(n, h)
+        res["ld_triangle 50000x1008"] = {
+            "ms": ms, "pairs_per_s": pairs / (ms * 1e-3), "fmt": fmt, "verified_against": "popcount kernel, every cell",
+            "results_equal": same,
+            "roofline_hbm": {"bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": alg},
+            "frac_of_fp4_peak": 2.0 * h * pairs / (ms * 1e-3) / 1e12 / MFMA_FP4_PEAK_TOPS}
+        del o, p
+        torch.cuda.empty_cache()
+    except Exception as exc:   # noqa: BLE001  (a reported extra, never a reason to lose the bench line)
+        res["ld_triangle 50000x1008"] = {"error": f"{type(exc).__name__}: {exc}"}
+    # ---- configs[2]: ld_area, 100 000 SNPs, +-500 kb, r2 >= 0.8, every SNP a query ----
+    try:
+        n, h = 100000, 5008
+        p = PackedPanel.from_codes(synth.synth_codes_device(n, h, seed=synth.BENCH_SEED, device=dev))
+        pos = torch.as_tensor(synth.synth_positions(n, step=500)).to(dev)
+        hits = ld_area(p, pos, None, 500000, "r_square", 0.8)
+        for _ in range(2):
+            ld_area(p, pos, None, 500000, "r_square", 0.8, check_positions=False)
+        torch.cuda.synchronize()
+        reps, ev, scan_ms = 5, [], 0.0
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            hits = ld_area(p, pos, None, 500000, "r_square", 0.8, check_positions=False, events=ev)
+            torch.cuda.synchronize()
+            scan_ms += ev[0].elapsed_time(ev[1])
+        wall = (time.perf_counter() - t0) / reps
+        old = ops.get_area_path()
+        try:
+            ops.set_area_path("popcount")                        # the independent scan kernel
+            ref = ld_area(p, pos, None, 500000, "r_square", 0.8, check_positions=False)
+        finally:
+            ops.set_area_path(old)
+        same = bool(len(ref) == len(hits) and torch.equal(ref.query, hits.query) and torch.equal(ref.oppos, hits.oppos)
+                    and torch.equal(ref.ld32.view(torch.int32), hits.ld32.view(torch.int32)))
+        n_pairs = hits.n_pairs
+        res["ld_area 100000 +-500kb r2>=0.8"] = {
+            "end_to_end_ms": wall * 1e3, "ordered_pairs": n_pairs, "ordered_pairs_per_s": n_pairs / wall, "hits": len(hits),
+            "scan_ms": scan_ms / reps, "scan": "ldx_area_dev: query mask, band plan, FP4 band kernel (HIP events)",
+            "end_to_end": "positions resident on the device; scan + count / offsets / scatter / order kernels + one host read",
+            "verified_against": "popcount scan, every hit in order", "results_equal": same}
+        del p, hits, ref
+        torch.cuda.empty_cache()
+    except Exception as exc:   # noqa: BLE001
+        res["ld_area 100000 +-500kb r2>=0.8"] = {"error": f"{type(exc).__name__}: {exc}"}
+    # ---- pack and host-to-device of the bench panel's codes (SURVEY 8d: reported separately, not in pairs/s) ----
+    try:
+        ns, nh = bench_codes.shape
+        pk = PackedPanel.empty(ns, nh, device=dev)
+        pk.pack_from(bench_codes)
+        torch.cuda.synchronize()
+        a, c = events()
+        a.record()
+        for _ in range(20):
+            pk.pack_from(bench_codes)
+        c.record()
+        torch.cuda.synchronize()
+        pack_ms = a.elapsed_time(c) / 20
+        host = bench_codes.cpu().pin_memory()
+        dst = torch.empty_like(bench_codes)
+        dst.copy_(host, non_blocking=True)
+        torch.cuda.synchronize()
+        a, c = events()
+        a.record()
+        for _ in range(5):
+            dst.copy_(host, non_blocking=True)
+        c.record()
+        torch.cuda.synchronize()
+        h2d_ms = a.elapsed_time(c) / 5
+        res["ingest"] = {"pack_ms": pack_ms, "h2d_ms": h2d_ms, "codes_bytes": int(bench_codes.numel()),
+                         "pack_gb_per_s_in": bench_codes.numel() / (pack_ms * 1e-3) / 1e9,
+                         "h2d_gb_per_s": bench_codes.numel() / (h2d_ms * 1e-3) / 1e9,
+                         "note": f"int8 codes [{ns}][{nh}] of the bench panel: pinned host -> device, then pack_codes + "
+                                 "snp_stats on the device; outside the timed region (the panel stays resident across steps)"}
+    except Exception as exc:   # noqa: BLE001
+        res["ingest"] = {"error": f"{type(exc).__name__}: {exc}"}
+    return res
 
 
 # ------------------------------------------------------------------------------------------ one rank
@@ -346,17 +506,35 @@ def run_rank(args):
     check = ld_triangle(panel, unit_range=(u0, u1), fmt=fmt)
     torch.cuda.synchronize()
     if not torch.equal(check.cells.view(torch.int32), out.cells.view(torch.int32)):
-        raise SystemExit("bench.py: the timed steps did not reproduce the triangle (stale or skipped work)")
+        print("bench.py: the timed steps did not reproduce the triangle (stale or skipped work)", file=sys.stderr, flush=True)
+        sys.stdout.flush()
+        os._exit(RC_VERIFY)     # a distinct code the launcher propagates and never retries
     del check
 
     value = n_pairs * args.steps / dt
+    # which devices did the ranks really run on?  (uuid where the runtime has one, else the PCI address)
+    props = torch.cuda.get_device_properties(dev)
+    dev_id = str(getattr(props, "uuid", "") or "") or \
+        f"pci {getattr(props, 'pci_domain_id', 0)}:{getattr(props, 'pci_bus_id', '?')}:{getattr(props, 'pci_device_id', '?')}"
+    dev_ids = [dev_id]
+    if use_dist and world > 1:
+        dev_ids = [None] * world
+        dist.all_gather_object(dev_ids, dev_id)
+    nccl_version = None
+    if use_dist and args.backend == "nccl":
+        try:
+            nccl_version = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception:   # noqa: BLE001
+            nccl_version = "unknown"
     # ---- roofline of the dominant kernel, per launch, this rank's share ----
     my_pairs = n_pairs / world
     kern_s = kern_ms_max * 1e-3
     alg_bytes = float(cell_bytes) * my_pairs + lib.ldx_plane_bytes(n_snps, n_hap)   # result cells + the ALT plane read once
     alg_ops = 2.0 * n_hap * my_pairs                                    # multiply-adds x 2 (2*H per pair)
     lane_ops = 2.0 * math.ceil(n_hap / 32) * my_pairs                   # v_and_b32 + v_bcnt_u32_b32 per 32 haplotypes
-    traffic, traffic_src = None, None
+    traffic, traffic_src, traffic_head, traffic_ksrc = None, None, None, None
+    from ld_tools_amd.build import source_digest
+    kernel_src = source_digest()            # sha256 of csrc/ + include/ldx.h as they are in this tree
     tfile = ROOT / "profiles" / "traffic.json"
     if tfile.exists():
         try:
@@ -365,15 +543,19 @@ def run_rank(args):
                     and rec.get("path") == path and rec.get("fmt") == fmt):
                 traffic = rec.get("hbm_bytes_per_launch")
                 traffic_src = f"profiles/traffic.json ({rec.get('profile', '?')}; rocprofv3 PMC, not measured in this run)"
+                traffic_head = rec.get("head")               # the commit the counters were taken at
+                traffic_ksrc = rec.get("kernel_src")         # ... and the digest of the kernel sources then
         except (ValueError, OSError):
             pass
+    provenance = {"traffic_head": traffic_head, "traffic_kernel_src": traffic_ksrc, "kernel_src": kernel_src,
+                  "traffic_is_of_this_kernel": (traffic_ksrc == kernel_src) if traffic is not None else None}
     hbm = {"bound": "hbm", "achieved": alg_bytes / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": alg_bytes / kern_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-           "algorithmic_bytes": alg_bytes}
+           "algorithmic_bytes": alg_bytes, **provenance}
     if path in ("fp4", "mfma"):   # the counting runs on the matrix pipe: that ceiling governs
         peak = MFMA_FP4_PEAK_TOPS if path == "fp4" else MFMA_I8_PEAK_TOPS
         roofline = {"bound": "mfma", "achieved": alg_ops / kern_s / 1e12, "peak": peak, "unit": "TOP/s",
-                    "frac": alg_ops / kern_s / 1e12 / peak, "traffic": traffic, "traffic_source": traffic_src,
+                    "frac": alg_ops / kern_s / 1e12 / peak, "traffic": traffic, "traffic_source": traffic_src, **provenance,
                     "kernel": "triangle_mfma_kernel", "kernel_ms": kern_ms_max, "kernel_ms_min_rank": kern_ms_min,
                     "algorithmic_ops": alg_ops, "ops_per_pair": 2 * n_hap,
                     "pipe": ("v_mfma_f32_32x32x64_f8f6f4, FP4 operands (dense peak 10 POP/s)" if path == "fp4"
@@ -406,8 +588,13 @@ def run_rank(args):
                    "launch": "HIP graph of the K steps, output verified after the timed region" if graph is not None else "eager",
                    "settle_steps": settle_done,   # untimed, beyond --warmup: the timed region starts at sustained clocks
                    "sharding": "none" if world == 1 else f"row-block shards, all-gather, pass list / {world}",
-                   "rccl_ranks": dist.get_world_size() if use_dist else 1,
+                   # ranks that met over RCCL (null when the group is not an RCCL group: gloo rehearsals, no group at N = 1)
+                   "rccl_ranks": dist.get_world_size() if (use_dist and args.backend == "nccl") else None,
+                   "group_ranks": dist.get_world_size() if use_dist else 1,
                    "backend": args.backend if use_dist else None,
+                   "nccl_version": nccl_version,
+                   "n_distinct_devices": len(set(dev_ids)),
+                   "devices": sorted(set(str(d) for d in dev_ids)),
                    "exchange": ("none" if not use_dist else "per step, overlapped with the previous step's kernel"
                                 if pipe is not None else "per step, before the kernel")},
         "roofline": roofline,
@@ -494,6 +681,8 @@ def run_rank(args):
             del outs
         except Exception as exc:   # noqa: BLE001  (an extra)
             line["other_paths"]["two_streams"] = {"error": f"{type(exc).__name__}: {exc}"}
+    if world == 1 and not use_dist and not args.no_other_workloads:
+        line["other_workloads"] = other_workloads(torch, dev, fmt, codes_local)
     if world > 1 and not args.no_single_gpu_leg:
         # strong-scaling reference: the WHOLE workload on rank 0's GPU alone, a few steps (the other ranks wait)
         single = None

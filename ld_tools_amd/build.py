@@ -32,6 +32,18 @@ def hipcc() -> str:
     return exe
 
 
+def source_digest() -> str:
+    """sha256 (16 hex digits) of the kernel sources and headers as they are in this tree: bench.py prints it next to the
+    digest recorded with profiles/traffic.json, so a counter record taken from an older kernel is visible as such."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted([CSRC / s for s in SOURCES] + HEADERS):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 def stale() -> bool:
     if not LIB.exists():
         return True

@@ -136,15 +136,23 @@ def fused_gather_start(local, slabs, slab_bytes: int, dev, group=None, stage=Non
         stage = (torch.zeros(big * per_slab, dtype=torch.uint8, device=dev),
                  torch.empty(world * big * per_slab, dtype=torch.uint8, device=dev))
     send, recv = stage
-    mine = slabs[rank]
+    fill_shard(send, local, slabs[rank], slabs, slab_bytes, with_ref)
+    work = dist.all_gather_into_tensor(recv, send, group=group, async_op=async_op)
+    return stage, (work if async_op else None)
+
+
+def fill_shard(send, local, mine: int, slabs, slab_bytes: int, with_ref: bool) -> None:
+    """One rank's byte shard of the fused exchange: [ALT: big slabs | acnt | rcnt (| REF: big slabs)] with this rank's
+    ``mine`` slabs at the front of every piece (the rest of a piece is padding nobody reads)."""
+    import torch
+
+    _, cnt_bytes, _, o_acnt, o_rcnt, o_ref = _gather_layout(slabs, slab_bytes, with_ref)
     if local is not None and mine:
         send[: mine * slab_bytes] = local["alt"][: mine * slab_bytes]
         send[o_acnt: o_acnt + mine * cnt_bytes] = local["acnt"][: mine * SLAB].view(torch.uint8)
         send[o_rcnt: o_rcnt + mine * cnt_bytes] = local["rcnt"][: mine * SLAB].view(torch.uint8)
         if with_ref:
             send[o_ref: o_ref + mine * slab_bytes] = local["ref"][: mine * slab_bytes]
-    work = dist.all_gather_into_tensor(recv, send, group=group, async_op=async_op)
-    return stage, (work if async_op else None)
 
 
 def fused_gather_finish(full, stage, slabs, slab_bytes: int, work=None):

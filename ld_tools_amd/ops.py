@@ -290,7 +290,7 @@ class AreaHits:
 
 def ld_area(panel: PackedPanel, positions, queries: Optional[Sequence[int]] = None, flank: int = 100000,
             measure: str = "r_square", thres: float = 0.8, hit_capacity: Optional[int] = None,
-            check_positions: bool = True) -> AreaHits:
+            check_positions: bool = True, events: Optional[list] = None) -> AreaHits:
     """Windowed scan of ld_area.py:152-276 over the panel.
 
     positions: ascending 1-based coordinates of the panel's SNPs (VCF order).  queries: panel
@@ -301,6 +301,8 @@ def ld_area(panel: PackedPanel, positions, queries: Optional[Sequence[int]] = No
 
     Everything up to the ordered hit list runs on the device (scan -> count per query -> scan -> scatter -> per-query
     order: ldx_area_dev + ldx_area_finish_dev); the host reads two integers at the end to size the result.
+    ``events`` (instrumentation, bench.py): a list that receives three torch events of the current stream -- before the
+    scan, between the scan (ldx_area_dev: mask, band plan, band kernel) and the finishing kernels, after them.
     """
     dev = panel.device
     if isinstance(positions, torch.Tensor):
@@ -339,13 +341,21 @@ def ld_area(panel: PackedPanel, positions, queries: Optional[Sequence[int]] = No
     while True:
         raw = torch.empty((cap, 4), dtype=torch.int32, device=dev)      # ldx_hit = {u32, u32, f32, f32}
         hits = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+        if events is not None:
+            del events[:]
+            events.extend(torch.cuda.Event(enable_timing=True) for _ in range(3))
+            events[0].record()
         check(lib.ldx_area_dev(panel.alt.data_ptr(), panel.fa.data_ptr(), panel.fr.data_ptr(), panel.q.data_ptr(),
                                panel.n_snps, panel.n_hap, pos.data_ptr(), q.data_ptr(), nq, int(flank),
                                MEASURES[measure], float(thres), raw.data_ptr(), cap, n_hits.data_ptr(),
                                ws.data_ptr(), ws_bytes, _stream_ptr()), "ldx_area_dev")
+        if events is not None:
+            events[1].record()
         check(lib.ldx_area_finish_dev(raw.data_ptr(), n_hits.data_ptr(), cap, panel.n_snps, hits.data_ptr(),
                                       offsets.data_ptr(), summary.data_ptr(), fin.data_ptr(), fin_bytes,
                                       _stream_ptr()), "ldx_area_finish_dev")
+        if events is not None:
+            events[2].record()
         total, reserved = (int(x) for x in summary.tolist())             # the one host round trip
         if reserved <= cap:
             break

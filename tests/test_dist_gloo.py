@@ -23,6 +23,65 @@ def test_two_rank_gloo_rehearsal():
     assert "GLOO_OK" in r.stdout
 
 
+def test_fused_exchange_places_the_shards_of_configs3():
+    """BASELINE configs[3] geometry, 100 000 SNPs x 5008 haplotypes over 8 ranks: 782 slabs as 98, ..., 98, 96 -- the
+    uneven case of fused_gather_finish (the rank-major concatenation is the full piece followed by padding).  The eight
+    ranks' byte shards are built with fill_shard exactly as fused_gather_start fills them and laid side by side as the
+    all-gather would; the placement must reproduce every slab image and every count, with and without the REF plane.
+    (The collective itself runs in the two-rank rehearsal above and in tests/test_gpu_dist.py.)"""
+    import numpy as np
+    import torch
+
+    sys.path.insert(0, str(ROOT))
+    from ld_tools_amd import dist as ldist
+
+    n_snps, n_hap, world = 100000, 5008, 8
+    parts = ldist.slab_partition(n_snps, world)
+    slabs = [(e - b + 127) // 128 for b, e in parts]
+    assert slabs == [98] * 7 + [96] and sum(slabs) == 782
+    slab_bytes = ldist.n_chunks(n_hap) * 128 * 16
+    assert slab_bytes == 80 * 1024
+    rng = np.random.default_rng(7)
+    n_pad = sum(slabs) * 128
+    for with_ref in (False, True):
+        planes = {k: torch.from_numpy(rng.integers(0, 256, size=sum(slabs) * slab_bytes, dtype=np.uint8))
+                  for k in (("alt", "ref") if with_ref else ("alt",))}
+        acnt = torch.from_numpy(rng.integers(0, 5009, size=n_pad, dtype=np.int32))
+        rcnt = torch.from_numpy(rng.integers(0, 5009, size=n_pad, dtype=np.int32))
+        big, cnt_bytes, per_slab, *_ = ldist._gather_layout(slabs, slab_bytes, with_ref)
+        recv = torch.full((world * big * per_slab,), 0xEE, dtype=torch.uint8)      # padding bytes must never be copied out
+        off = 0
+        for r, mine in enumerate(slabs):
+            local = {k: v[off * slab_bytes: (off + mine) * slab_bytes] for k, v in planes.items()}
+            local["acnt"] = acnt[off * 128: (off + mine) * 128]
+            local["rcnt"] = rcnt[off * 128: (off + mine) * 128]
+            ldist.fill_shard(recv[r * big * per_slab: (r + 1) * big * per_slab], local, mine, slabs, slab_bytes, with_ref)
+            off += mine
+        full = {k: torch.zeros_like(v) for k, v in planes.items()}
+        full["acnt"] = torch.zeros(n_pad, dtype=torch.int32)
+        full["rcnt"] = torch.zeros(n_pad, dtype=torch.int32)
+        ldist.fused_gather_finish(full, (None, recv), slabs, slab_bytes)
+        for k, v in planes.items():
+            assert torch.equal(full[k], v), k
+        assert torch.equal(full["acnt"], acnt) and torch.equal(full["rcnt"], rcnt)
+    # and an arbitrary split (third branch) on a small geometry
+    slabs = [2, 5, 0, 3]
+    sb = 2 * 128 * 16
+    alt = torch.arange(sum(slabs) * sb, dtype=torch.int64).to(torch.uint8)
+    cnt = torch.arange(sum(slabs) * 128, dtype=torch.int32)
+    big, cnt_bytes, per_slab, *_ = ldist._gather_layout(slabs, sb, False)
+    recv = torch.full((len(slabs) * big * per_slab,), 0xEE, dtype=torch.uint8)
+    off = 0
+    for r, mine in enumerate(slabs):
+        local = {"alt": alt[off * sb: (off + mine) * sb], "acnt": cnt[off * 128: (off + mine) * 128],
+                 "rcnt": cnt[off * 128: (off + mine) * 128] + 1}
+        ldist.fill_shard(recv[r * big * per_slab: (r + 1) * big * per_slab], local, mine, slabs, sb, False)
+        off += mine
+    full = {"alt": torch.zeros_like(alt), "acnt": torch.zeros_like(cnt), "rcnt": torch.zeros_like(cnt)}
+    ldist.fused_gather_finish(full, (None, recv), slabs, sb)
+    assert torch.equal(full["alt"], alt) and torch.equal(full["acnt"], cnt) and torch.equal(full["rcnt"], cnt + 1)
+
+
 def test_bench_launcher_fails_loudly_without_gpu():
     """`python bench.py --gpus 2` starts the ranks itself (a child torch.distributed.run, before any GPU call).  On a box
     without a GPU the ranks refuse to run -- there is no CPU path -- and the launcher must hand that on as a non-zero exit

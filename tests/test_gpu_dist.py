@@ -42,7 +42,11 @@ def test_bench_launches_its_own_ranks():
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and rec["config"]["rccl_ranks"] == 2
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "strong"
+    # a gloo rehearsal is NOT an RCCL run and must not read as one; both ranks sit on the one card
+    assert rec["config"]["rccl_ranks"] is None and rec["config"]["group_ranks"] == 2 and rec["config"]["backend"] == "gloo"
+    assert rec["config"]["nccl_version"] is None and rec["config"]["n_distinct_devices"] == 1
+    assert rec["retried"] is False and rec["first_attempt_rc"] == 0
     assert rec["config"]["workload"] == "ld_triangle 3000x5008" and rec["value"] > 0
     assert rec["config"]["single_gpu_same_workload"]["pairs_per_s"] > 0
     assert rec["roofline"]["kernel_ms"] >= rec["roofline"]["kernel_ms_min_rank"] > 0

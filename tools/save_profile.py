@@ -7,6 +7,7 @@
 import glob
 import json
 import shutil
+import subprocess
 import sys
 from pathlib import Path
 
@@ -30,8 +31,17 @@ if (src / "command.txt").exists():
     shutil.copy(src / "command.txt", dst / f"{tag}_command.txt")
 if (src / "traffic_counters.json").exists():
     rec = json.loads((src / "traffic_counters.json").read_text())
+    sys.path.insert(0, str(root))
+    from ld_tools_amd.build import source_digest
+    try:    # the commit whose tree went to the GPU box (run this right after the gpurun call, before editing on)
+        head = subprocess.run(["git", "rev-parse", "HEAD"], cwd=root, capture_output=True, text=True).stdout.strip()
+        dirty = bool(subprocess.run(["git", "status", "--porcelain", "--", "ld_tools_amd/csrc", "include"], cwd=root,
+                                    capture_output=True, text=True).stdout.strip())
+    except OSError:
+        head, dirty = None, None
     rec.update(workload=workload, gpus=gpus, path=path, fmt=fmt, profile=tag,
-               source=f"profiles/{rnd}/{tag}_rocprofv3_summary.txt")
+               source=f"profiles/{rnd}/{tag}_rocprofv3_summary.txt", head=head, kernel_sources_dirty=dirty,
+               kernel_src=source_digest())
     (dst / f"{tag}_traffic.json").write_text(json.dumps(rec, indent=1) + "\n")
     if "--no-traffic" not in sys.argv:
         (root / "profiles" / "traffic.json").write_text(json.dumps(rec, indent=1) + "\n")
