@@ -779,6 +779,74 @@ def test_triangle_100k_shard_of_eight(gpu):
     assert checked > 20000
 
 
+def test_config3_triangle_100k_all_eight_shards(gpu):
+    """BASELINE configs[3] at FULL size on one card: 100 000 SNPs x 5008 haplotypes, all eight unit ranges of
+    dist.unit_partition(100000, 8) one after the other (4 B cells + counts: 5 GB per shard, 5.0e9 pairs in all) -- what the
+    eight ranks compute, minus the RCCL hop (tests/test_gpu_dist.py, tests/test_dist_gloo.py).  Per shard: the FP4 kernel
+    and the popcount kernel agree on every cell and every count, the int8 kernel agrees on a sub-range of units, and rows
+    that fall into the shard match the C oracle; over the eight shards every unit is covered once and the n11 mass of
+    the whole triangle equals sum_h C(k_h, 2)."""
+    import torch
+    from ld_tools_amd import dist, ld_triangle, synth
+    from ld_tools_amd._lib import UNIT_PAIRS
+    from oracle import c_oracle
+
+    n, h = 100000, 5008
+    codes_d, p = _config_panel(n, h)
+    parts = dist.unit_partition(n, 8)
+    assert parts[0][0] == 0 and all(parts[k][1] == parts[k + 1][0] for k in range(7))
+    codes = codes_d.cpu().numpy()
+    o = c_oracle.Panel(codes)
+    npad = ((n + 127) // 128) * 128
+    G = npad // 8
+    rows_to_check = (130, 20011, 38000, 52001, 61007, 70001, 84444, 93000, 99999)
+    mass, checked, shards_checked = 0, 0, set()
+    for r, (u0, u1) in enumerate(parts):
+        a = ld_triangle(p, unit_range=(u0, u1), want_n11=True, fmt="k16", path="fp4")
+        assert a.k16.shape[0] == (u1 - u0) * UNIT_PAIRS
+        b = ld_triangle(p, unit_range=(u0, u1), want_n11=True, fmt="k16", path="popcount")
+        assert torch.equal(a.n11, b.n11), f"shard {r}: counts, FP4 vs popcount"
+        assert torch.equal(a.k16, b.k16), f"shard {r}: cells, FP4 vs popcount"
+        del b
+        plain = ld_triangle(p, unit_range=(u0, u1), fmt="k16", path="fp4")        # the product variant (fp32 tier + fallbacks)
+        assert torch.equal(plain.k16, a.k16), f"shard {r}: product variant"
+        del plain
+        s0 = u0 + (u1 - u0) // 3                                                  # the third kernel on 4000 units of the shard
+        c = ld_triangle(p, unit_range=(s0, s0 + 4000), fmt="k16", path="mfma")
+        lo = (s0 - u0) * UNIT_PAIRS
+        assert torch.equal(c.k16, a.k16[lo: lo + 4000 * UNIT_PAIRS]), f"shard {r}: int8 kernel"
+        del c
+        mass += int(a.n11.to(torch.int64).sum().item())
+        for row in rows_to_check:
+            cols = np.arange(row, dtype=np.int64)
+            t_ = cols // 128
+            u = t_ * G - 8 * t_ * (t_ - 1) + (row // 8 - 16 * t_)
+            m = (u >= u0) & (u < u1)
+            if not m.any():
+                continue
+            cm = cols[m]
+            assert np.array_equal(cm, np.arange(cm[0], cm[-1] + 1))               # a row's units inside a range are contiguous
+            idx = torch.from_numpy((u[m] - u0) * UNIT_PAIRS + (row % 8) * 128 + (cm % 128)).to(a.k16.device)
+            want_n = o.pair_counts(row, row + 1, int(cm[0]), int(cm[-1]) + 1)[0]
+            k = len(cm)
+            _, _, w_rsq, w_dp, w_flags = c_oracle.ld_from_counts_v(
+                h, want_n, np.full(k, o.acnt[row], np.uint32), np.full(k, o.rcnt[row], np.uint32), o.acnt[cm], o.rcnt[cm],
+                libm_pow=True)                                                    # var_1 = row, var_2 = column
+            assert np.array_equal(a.n11[idx].cpu().numpy().view(np.uint32), want_n)
+            cells = a.k16[idx].cpu().numpy().astype(np.int64) & 0xFFFF
+            int0 = np.stack([(w_flags & 2) != 0, (w_flags & 1) != 0], axis=1)
+            want_k = np.stack([np.rint(w_rsq * 1e4), np.rint(w_dp * 1e4)], axis=1).astype(np.int64)
+            assert np.array_equal(cells, np.where(int0, 0x8000, want_k)), (r, row)
+            checked += k
+            shards_checked.add(r)
+        del a
+        torch.cuda.empty_cache()
+    assert parts[-1][1] * UNIT_PAIRS >= n * (n - 1) // 2
+    assert checked > 400000 and len(shards_checked) >= 5
+    colsum = (codes_d == 1).sum(dim=0, dtype=torch.int64)
+    assert mass == int((colsum * (colsum - 1) // 2).sum().item())
+
+
 # ------------------------------------------------------------------ ld_area
 def test_area_matches_golden_drivers(gpu, area_path, drivers, panel_codes):
     from ld_tools_amd import PackedPanel, ld_area
