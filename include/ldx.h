@@ -216,8 +216,9 @@ size_t ldx_area_workspace_bytes(uint32_t n_snps, uint32_t n_hap, uint32_t n_quer
  * offsets[n_snps + 1] (hits of query row q are sorted[offsets[q] .. offsets[q + 1])).  n_reserved: the device counter
  * ldx_area_dev filled; sorted: capacity hit_cap; summary: device uint64 [2] = {number of hits, slots reserved}.
  * If summary[1] > hit_cap the scan overflowed its buffer: run both again with hit_cap >= summary[1].
+ * `raw` is CONSUMED: once its slots have been scattered it serves as the scratch the ordering of long hit lists writes to.
  * offsets must be 16-byte aligned, workspace 256-byte aligned. */
-int ldx_area_finish_dev(const ldx_hit *raw, const uint64_t *n_reserved, uint64_t hit_cap, uint32_t n_snps,
+int ldx_area_finish_dev(ldx_hit *raw, const uint64_t *n_reserved, uint64_t hit_cap, uint32_t n_snps,
                         ldx_hit *sorted, uint32_t *offsets, uint64_t *summary, void *workspace,
                         size_t workspace_bytes, void *stream);
 size_t ldx_area_finish_workspace_bytes(uint32_t n_snps);
@@ -244,7 +245,7 @@ int ldx_synth_codes_dev(int8_t *codes, uint32_t n_snps, uint32_t n_hap, size_t l
  * n = min(h1, h2) for the haplotype count, allele counts over the full vectors; any lengths >= 1).
  * counts[6] = {n, n11, a1, r1, a2, r2}; raw = unrounded; rounded = round(x, 4) as doubles, exact for any
  * magnitude; freq4[2] = round4(fa1), round4(fa2).  One H2D copy, ONE kernel (counts straight from the codes,
- * epilogue, rounding) and one 64-byte D2H copy per call, through device scratch cached per host thread. */
+ * epilogue, rounding) and one 80-byte D2H copy per call, through device scratch cached per host thread. */
 int ldx_calc_ld_host(const int8_t *g1, uint32_t h1, const int8_t *g2, uint32_t h2,
                      uint32_t counts[6], ldx_ld64 *raw, ldx_ld64 *rounded, double freq4[2],
                      uint8_t *flags);

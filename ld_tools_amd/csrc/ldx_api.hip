@@ -104,7 +104,7 @@ extern "C" uint64_t ldx_triangle_unit_of(uint32_t n_snps, uint32_t row, uint32_t
 // ---- calc_ld for one pair, host pointers (used by the backend/calc_ld.py drop-in; ld_lite.py:143) ----
 namespace ldx {
 
-struct CalcLdRecord {       // the 64 bytes that travel back
+struct CalcLdRecord {       // the 80 bytes that travel back (static_assert below)
     uint32_t counts[6];     // n, n11, a1, r1, a2, r2
     uint32_t flags;
     uint32_t pad;

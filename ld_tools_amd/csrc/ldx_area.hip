@@ -352,13 +352,24 @@ __global__ void area_scatter_kernel(const ldx_hit *__restrict__ raw, const unsig
     if (h.query < n_snps) sorted[atomicAdd(&cursor[h.query], 1u)] = h;
 }
 
-// one thread per query: its hits (a handful) into ascending opposing row = VCF order (ld_area.py:215-217)
-__global__ void area_order_kernel(const uint32_t *__restrict__ offsets, uint32_t n_snps, ldx_hit *__restrict__ sorted)
+// A query's hits into ascending opposing row = VCF order (ld_area.py:215-217).  The scatter kernel places them in the
+// order its atomics happened to run, i.e. in no order.  One thread per query sorts the usual handful in place
+// (insertion sort, <= kOrderShort hits); a query with more (low thresholds: up to a whole window, thousands) goes on a
+// list and is ordered by a whole workgroup (area_order_long_kernel) -- a single thread would need ~n^2 / 2 dependent
+// global-memory moves there, milliseconds to seconds for one slow lane.
+constexpr uint32_t kOrderShort = 32u, kOrderTile = 2048u;
+
+__global__ void area_order_kernel(const uint32_t *__restrict__ offsets, uint32_t n_snps, ldx_hit *__restrict__ sorted,
+                                  uint32_t *__restrict__ long_list, uint32_t *__restrict__ n_long)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_snps) return;
     const uint32_t b = offsets[k], e = offsets[k + 1u];
-    for (uint32_t i = b + 1u; i < e; ++i) {   // insertion sort: segments are short and arrive nearly ordered
+    if (e - b > kOrderShort) {
+        long_list[atomicAdd(n_long, 1u)] = k;
+        return;
+    }
+    for (uint32_t i = b + 1u; i < e; ++i) {
         const ldx_hit h = sorted[i];
         uint32_t j = i;
         while (j > b && sorted[j - 1u].oppos > h.oppos) {
@@ -369,16 +380,55 @@ __global__ void area_order_kernel(const uint32_t *__restrict__ offsets, uint32_t
     }
 }
 
+// Long segments, one workgroup at a time per listed query: rank sort.  A hit's place is the number of hits of its query
+// with a smaller opposing row (the rows of one query are distinct; ties, which cannot happen, would be broken by
+// position); every thread ranks one hit per round against all keys, staged through LDS in tiles, and writes it to that
+// place in `scratch` (the raw slot buffer, consumed by the scatter kernel before); the segment is then copied back.
+// n^2 / 256 key compares per thread instead of n^2 / 2 dependent moves in one.
+__global__ void __launch_bounds__(256) area_order_long_kernel(const uint32_t *__restrict__ offsets,
+                                                              const uint32_t *__restrict__ long_list,
+                                                              const uint32_t *__restrict__ n_long, ldx_hit *__restrict__ sorted,
+                                                              ldx_hit *__restrict__ scratch)
+{
+    __shared__ uint32_t keys[kOrderTile];
+    const uint32_t count = *n_long;
+    for (uint32_t w = blockIdx.x; w < count; w += gridDim.x) {   // block-uniform
+        const uint32_t k = long_list[w], b = offsets[k], n = offsets[k + 1u] - b;
+        for (uint32_t i0 = 0; i0 < n; i0 += blockDim.x) {        // block-uniform: every thread reaches every barrier
+            const uint32_t i = i0 + threadIdx.x;
+            ldx_hit h{};
+            if (i < n) h = sorted[b + i];
+            uint32_t rank = 0;
+            for (uint32_t t0 = 0; t0 < n; t0 += kOrderTile) {
+                const uint32_t tn = n - t0 < kOrderTile ? n - t0 : kOrderTile;
+                block_sync();
+                for (uint32_t j = threadIdx.x; j < tn; j += blockDim.x) keys[j] = sorted[b + t0 + j].oppos;
+                block_sync();
+                if (i < n)
+                    for (uint32_t j = 0; j < tn; ++j) {
+                        const uint32_t kj = keys[j];
+                        rank += (kj < h.oppos) || (kj == h.oppos && t0 + j < i);
+                    }
+            }
+            if (i < n) scratch[b + rank] = h;
+        }
+        __threadfence_block();
+        block_sync();                                            // the ordered segment is complete in `scratch`
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) sorted[b + i] = scratch[b + i];
+        block_sync();
+    }
+}
+
 }  // namespace ldx
 
 using namespace ldx;
 
 extern "C" size_t ldx_area_finish_workspace_bytes(uint32_t n_snps)
 {
-    return 2u * (((size_t)n_snps + 1u) * 4u + 255u) / 256u * 256u;   // counts, cursor
+    return 3u * ((((size_t)n_snps + 1u) * 4u + 255u) / 256u * 256u);   // counts, cursor, {number of long queries, their rows}
 }
 
-extern "C" int ldx_area_finish_dev(const ldx_hit *raw, const uint64_t *n_reserved, uint64_t hit_cap, uint32_t n_snps,
+extern "C" int ldx_area_finish_dev(ldx_hit *raw, const uint64_t *n_reserved, uint64_t hit_cap, uint32_t n_snps,
                                    ldx_hit *sorted, uint32_t *offsets, uint64_t *summary, void *workspace,
                                    size_t workspace_bytes, void *stream)
 {
@@ -391,7 +441,9 @@ extern "C" int ldx_area_finish_dev(const ldx_hit *raw, const uint64_t *n_reserve
     hipStream_t s = (hipStream_t)stream;
     const size_t vec = (((size_t)n_snps + 1u) * 4u + 255u) / 256u * 256u;
     uint32_t *counts = (uint32_t *)workspace, *cursor = (uint32_t *)((char *)workspace + vec);
+    uint32_t *n_long = (uint32_t *)((char *)workspace + 2u * vec), *long_list = n_long + 1;   // [1 + n_snps]
     LDX_HIP(hipMemsetAsync(counts, 0, ((size_t)n_snps + 1u) * 4u, s));
+    LDX_HIP(hipMemsetAsync(n_long, 0, sizeof(uint32_t), s));
     const uint32_t slot_blocks = (uint32_t)((hit_cap + 255u) / 256u);
     if (slot_blocks) {
         area_count_kernel<<<slot_blocks, 256, 0, s>>>(raw, (const unsigned long long *)n_reserved, hit_cap, n_snps, counts);
@@ -404,7 +456,12 @@ extern "C" int ldx_area_finish_dev(const ldx_hit *raw, const uint64_t *n_reserve
         area_scatter_kernel<<<slot_blocks, 256, 0, s>>>(raw, (const unsigned long long *)n_reserved, hit_cap, n_snps, cursor,
                                                         sorted);
         LDX_HIP(hipGetLastError());
-        area_order_kernel<<<(n_snps + 255u) / 256u, 256, 0, s>>>(offsets, n_snps, sorted);
+        area_order_kernel<<<(n_snps + 255u) / 256u, 256, 0, s>>>(offsets, n_snps, sorted, long_list, n_long);
+        LDX_HIP(hipGetLastError());
+        // queries with more than kOrderShort hits (none at the usual thresholds: the kernel then returns at once); the raw
+        // slot buffer has been consumed by the scatter kernel and serves as the out-of-place target
+        const uint32_t long_blocks = n_snps < 1024u ? n_snps : 1024u;
+        area_order_long_kernel<<<long_blocks, 256, 0, s>>>(offsets, long_list, n_long, sorted, raw);
         LDX_HIP(hipGetLastError());
     }
     return LDX_OK;

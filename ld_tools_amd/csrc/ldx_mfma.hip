@@ -1123,7 +1123,9 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
 // One ticket-counter pair per (device, stream): launches of one stream are ordered, so they may share it; launches of
 // different streams (or devices) may overlap, so they must not.  The pairs live in the per-device instance of g_sched;
 // a slot is zeroed ONCE, on the stream that acquires it, and from then on every launch leaves it re-armed (the last
-// workgroup out resets both words), so a launch costs no memset node.
+// workgroup out resets both words), so a launch costs no memset node.  A slot is NEVER taken away from its stream: a
+// captured HIP graph has the slot's address baked into its kernel nodes, and a live stream may have a launch in flight on
+// it -- the 257th distinct stream of a device gets LDX_E_UNSUPPORTED instead of somebody else's counters.
 static int acquire_sched(hipStream_t s, uint32_t **sched)
 {
     struct Key {
@@ -1136,8 +1138,7 @@ static int acquire_sched(hipStream_t s, uint32_t **sched)
     };
     struct PerDevice {
         uint32_t (*pool)[kSchedWords] = nullptr;   // this device's g_sched
-        uint32_t next_slot = 0;
-        Key owner[kSchedSlots] = {};
+        uint32_t next_slot = 0;                    // slots handed out so far (never reclaimed)
     };
     static std::mutex sched_mutex;
     static std::unordered_map<Key, uint32_t, KeyHash> sched_slot;
@@ -1157,10 +1158,14 @@ static int acquire_sched(hipStream_t s, uint32_t **sched)
         }
         const Key key{dev, s};
         auto it = sched_slot.find(key);
-        if (it == sched_slot.end()) {   // a new stream takes the next slot round-robin; the slot's previous owner (a
-            slot = pd.next_slot++ % kSchedSlots;   // stream last seen >= 256 new streams ago) loses its entry
-            if (pd.next_slot > kSchedSlots) sched_slot.erase(pd.owner[slot]);
-            pd.owner[slot] = key;
+        if (it == sched_slot.end()) {   // a new stream takes the next free slot, for the life of the process
+            if (pd.next_slot >= kSchedSlots) {
+                set_error("ld_triangle on the matrix pipe: more than %u distinct streams on device %d (one ticket-counter "
+                          "slot per stream, never reclaimed); reuse streams, or use LDX_PATH_POPCOUNT on the others",
+                          kSchedSlots, dev);
+                return LDX_E_UNSUPPORTED;
+            }
+            slot = pd.next_slot++;
             sched_slot.emplace(key, slot);
             fresh = true;
         } else {

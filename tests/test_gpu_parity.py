@@ -881,8 +881,11 @@ def test_area_banded_against_oracle(gpu, area_path):
     pos = synth.synth_positions(n, step=500)
     p = PackedPanel.from_codes(codes)
     o = c_oracle.Panel(codes)
+    # the last two: LONG hit lists per query (a threshold of 0 keeps the whole window: 1600 hits, then all 2999 = more than
+    # one key tile of the workgroup rank sort that orders lists of more than 32 hits, csrc/ldx_area.hip)
     for (queries, flank, measure, thres) in [(None, 20000, "r_square", 0.8), (list(range(0, n, 7)), 150000, "d_prime", 1.0),
-                                             (None, 3000, "r_square", 0.0)]:
+                                             (None, 3000, "r_square", 0.0), (None, 400000, "r_square", 0.0),
+                                             (list(range(0, n, 50)), 10 ** 7, "d_prime", 0.0)]:
         hits = ld_area(p, pos, queries, flank, measure, thres)
         qs = np.arange(n) if queries is None else np.array(queries)
         hq, ho, hr, hd, hf = o.area(pos, qs, flank, 0 if measure == "r_square" else 1, thres, libm_pow=True)
