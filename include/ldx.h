@@ -44,6 +44,11 @@ extern "C" {
 #define LDX_GROUP_ROWS 8u          /* SNP rows a wavefront pairs against one j-tile per unit */
 #define LDX_CHUNK_HAPS 128u        /* haplotypes per 16-byte chunk */
 #define LDX_UNIT_PAIRS (LDX_SLAB_ROWS * LDX_GROUP_ROWS)   /* 1024 result cells per unit */
+/* Cell order INSIDE a unit (8 rows x 128 columns): row-major, r8 = row % 8, c = column % 128.  Every producer and consumer
+ * of strip output goes through this macro (ld_tools_amd/_lib.py: cell_offset).  A column-quad-major order (32 quads of
+ * 8 rows x 4 columns, which lets the matrix kernel write 16 bytes per lane in whole 128-byte lines once its operand roles are
+ * swapped) was built and measured in round 3: slower on every shape (profiles/r03/quad_major_layout_ab.log). */
+#define LDX_CELL_OFFSET(r8, c) ((r8) * LDX_SLAB_ROWS + (c))
 #define LDX_MAX_HAPS 10240u        /* one j-tile (128 rows, all chunks) must fit 160 KiB of LDS */
 
 /* error codes */
@@ -102,11 +107,12 @@ size_t ldx_plane_bytes(uint32_t n_snps, uint32_t n_hap);   /* bytes of one tiled
 uint32_t ldx_padded_snps(uint32_t n_snps);                 /* n_slabs * 128 */
 /* Triangle work units.  Unit u of the strict lower triangle pairs the 8 rows of group g with the
  * 128 columns of j-tile t, u = t*G - 8*t*(t-1) + (g - 16*t), G = padded_snps/8, g >= 16*t.  Result
- * cell (row i, column j), i > j, lives at element u*1024 + (i % 8)*128 + (j % 128) of the strip
- * output, t = j/128, g = i/8. */
+ * cell (row i, column j), i > j, lives at element u*1024 + LDX_CELL_OFFSET(i % 8, j % 128) of the strip
+ * output, t = j/128, g = i/8 (ldx_triangle_cell_index does the arithmetic). */
 uint64_t ldx_triangle_units(uint32_t n_snps);
 uint64_t ldx_triangle_unit_of(uint32_t n_snps, uint32_t row, uint32_t col);  /* requires row > col */
 uint64_t ldx_triangle_tile_base(uint32_t n_snps, uint32_t tile);             /* first unit of j-tile */
+uint64_t ldx_triangle_cell_index(uint32_t n_snps, uint32_t row, uint32_t col); /* element of cell (row > col) in the full strip output */
 
 /* ---- packing: the genotype lists of ld_triangle.py:160-186 / ld_area.py:182-187,230-235 ---- */
 /* codes: int8 [n_snps][ld_codes], 1 = ALT, 0 = REF, anything else = neither (None, 2nd ALT...).

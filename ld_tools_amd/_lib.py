@@ -18,6 +18,14 @@ LIB_PATH = Path(os.environ.get("LDX_LIB") or Path(__file__).resolve().parent / "
 SLAB_ROWS = 128
 GROUP_ROWS = 8
 UNIT_PAIRS = SLAB_ROWS * GROUP_ROWS
+
+
+def cell_offset(r8, c):
+    """LDX_CELL_OFFSET of include/ldx.h: element of cell (row % 8, column % 128) inside its unit (row-major).  Works on
+    ints and numpy arrays."""
+    return r8 * SLAB_ROWS + c
+
+
 MAX_HAPS = 10240
 FLAG_DPRIME_INT0 = 1
 FLAG_RSQ_INT0 = 2
@@ -86,6 +94,7 @@ SIGNATURES = {
     "ldx_triangle_units": (_u64, [_u32]),
     "ldx_triangle_unit_of": (_u64, [_u32, _u32, _u32]),
     "ldx_triangle_tile_base": (_u64, [_u32, _u32]),
+    "ldx_triangle_cell_index": (_u64, [_u32, _u32, _u32]),
     "ldx_pack_codes_dev": (_int, [_vp, _u32, _u32, _sz, _vp, _vp, _vp, _vp, _vp]),
     "ldx_tile_plane_dev": (_int, [_vp, _u32, _u32, _sz, _vp, _vp, _vp]),
     "ldx_snp_stats_dev": (_int, [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp]),

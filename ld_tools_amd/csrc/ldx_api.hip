@@ -101,6 +101,11 @@ extern "C" uint64_t ldx_triangle_unit_of(uint32_t n_snps, uint32_t row, uint32_t
     return tile_base(t, T * kGroupsPerSlab) + (g - t * kGroupsPerSlab);
 }
 
+extern "C" uint64_t ldx_triangle_cell_index(uint32_t n_snps, uint32_t row, uint32_t col)
+{
+    return ldx_triangle_unit_of(n_snps, row, col) * LDX_UNIT_PAIRS + LDX_CELL_OFFSET(row % kGroup, col % kSlab);
+}
+
 // ---- calc_ld for one pair, host pointers (used by the backend/calc_ld.py drop-in; ld_lite.py:143) ----
 namespace ldx {
 

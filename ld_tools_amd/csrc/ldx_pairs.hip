@@ -80,7 +80,7 @@ triangle_kernel(const uint4 *__restrict__ alt, const double *__restrict__ fa, co
                 for (int jj = 0; jj < 2; ++jj) {
                     const uint32_t j = jj ? j1 : j0;
                     const bool valid = (i > j) && (i < n_snps);   // ld_triangle.py:149-150
-                    const size_t o = obase + (size_t)r * kSlab + jj * 64u + lane;
+                    const size_t o = obase + LDX_CELL_OFFSET((uint32_t)r, jj * 64u + lane);
                     Cell res = zero_cell<Cell>();
                     ldx_ld64 rw = {0.0, 0.0};
                     if (valid) {
@@ -326,7 +326,7 @@ __global__ void triangle_dense_kernel(const Cell *__restrict__ strips, uint32_t 
         const uint64_t G = (uint64_t)n_slabs * kGroupsPerSlab;
         const uint32_t t = j / kSlab, g = i / kGroup;
         const uint64_t u = tile_base(t, G) + (g - t * kGroupsPerSlab);
-        const Cell c = strips[u * LDX_UNIT_PAIRS + (i % kGroup) * kSlab + (j % kSlab)];
+        const Cell c = strips[u * LDX_UNIT_PAIRS + LDX_CELL_OFFSET(i % kGroup, j % kSlab)];
         double k;
         v = dense_value(c, measure, &k);
         // ld_triangle.py:223-225 compares the rounded value k/10^4 with the threshold; k_thres is the

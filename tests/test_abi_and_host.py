@@ -119,6 +119,21 @@ def test_geometry_helpers():
     assert 10000 * 9999 // 2 <= cells < 1.04 * 10000 * 9999 // 2
 
 
+def test_unit_cell_order_is_a_permutation_and_matches_the_library():
+    """LDX_CELL_OFFSET (include/ldx.h): every (row % 8, column % 128) gets its own element of the unit's 1024; the library's
+    ldx_triangle_cell_index and the Python helper agree (every producer and consumer of strip output goes through them)."""
+    from ld_tools_amd import _lib
+
+    r, c = np.meshgrid(np.arange(8), np.arange(128), indexing="ij")
+    off = _lib.cell_offset(r, c)
+    assert sorted(off.ravel().tolist()) == list(range(1024))
+    L = _lib.lib
+    for n in (130, 1000, 10000):
+        for row, col in ((1, 0), (n - 1, 0), (n - 1, n - 2), (129, 127), (n // 2, n // 3)):
+            u = L.ldx_triangle_unit_of(n, row, col)
+            assert L.ldx_triangle_cell_index(n, row, col) == u * 1024 + int(_lib.cell_offset(row % 8, col % 128))
+
+
 def test_device_calls_fail_loudly_without_gpu():
     """No GPU here: the product must raise, not compute on the CPU."""
     import torch

@@ -729,7 +729,7 @@ def test_triangle_100k_shard_of_eight(gpu):
     shard equals what the rectangular-block kernel counts for the same cells."""
     import torch
     from ld_tools_amd import PackedPanel, dist, ld_triangle, ops, synth
-    from ld_tools_amd._lib import UNIT_PAIRS
+    from ld_tools_amd._lib import UNIT_PAIRS, cell_offset
     from oracle import c_oracle
 
     n, h = 100000, 5008
@@ -761,7 +761,7 @@ def test_triangle_100k_shard_of_eight(gpu):
         m = (u >= u0) & (u < u1)
         if not m.any():
             continue
-        idx = (u[m] - u0) * UNIT_PAIRS + (row % 8) * 128 + (cols[m] % 128)
+        idx = (u[m] - u0) * UNIT_PAIRS + cell_offset(row % 8, cols[m] % 128)
         c = cols[m]
         want_n = o.pair_counts(row, row + 1, int(c[0]), int(c[-1]) + 1)[0]        # the columns of a row's units are contiguous
         assert len(want_n) == len(c)
@@ -788,7 +788,7 @@ def test_config3_triangle_100k_all_eight_shards(gpu):
     the whole triangle equals sum_h C(k_h, 2)."""
     import torch
     from ld_tools_amd import dist, ld_triangle, synth
-    from ld_tools_amd._lib import UNIT_PAIRS
+    from ld_tools_amd._lib import UNIT_PAIRS, cell_offset
     from oracle import c_oracle
 
     n, h = 100000, 5008
@@ -826,7 +826,7 @@ def test_config3_triangle_100k_all_eight_shards(gpu):
                 continue
             cm = cols[m]
             assert np.array_equal(cm, np.arange(cm[0], cm[-1] + 1))               # a row's units inside a range are contiguous
-            idx = torch.from_numpy((u[m] - u0) * UNIT_PAIRS + (row % 8) * 128 + (cm % 128)).to(a.k16.device)
+            idx = torch.from_numpy((u[m] - u0) * UNIT_PAIRS + cell_offset(row % 8, cm % 128)).to(a.k16.device)
             want_n = o.pair_counts(row, row + 1, int(cm[0]), int(cm[-1]) + 1)[0]
             k = len(cm)
             _, _, w_rsq, w_dp, w_flags = c_oracle.ld_from_counts_v(
