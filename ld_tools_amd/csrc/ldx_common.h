@@ -17,12 +17,14 @@ constexpr uint32_t kGroupsPerSlab = kSlab / kGroup;   // 16
 
 void set_error(const char *fmt, ...);
 
-// Workgroup barrier that first drains THIS wave's LDS traffic.  hipcc (ROCm 7.2) lowers __syncthreads() to a fence of the
-// local address space + s_barrier, and for such a fence LLVM's gfx9 memory model emits NO s_waitcnt lgkmcnt(0): it takes
-// the LDS operations of all waves to execute in one total order.  On gfx950 with two workgroups per CU that did not
-// hold: a ds_write (the pass ticket) issued just before the barrier was, about once in 10^6 barriers, not yet visible
-// to a ds_read another wave issued right behind it -- that wave then redid an old pass and left its own undone
-// (tools/gpu_soak.py).  Every barrier in these sources goes through here.
+// Workgroup barrier that first drains THIS wave's LDS traffic.  Symptom it removes: about once in 10^6 barriers a
+// ds_write issued just before the barrier (the pass ticket, by wave 0) was not yet visible to the ds_read another wave
+// issued right behind it -- that wave then redid an old pass and left its own undone (tools/gpu_soak.py).
+// ISA evidence (profiles/r03/syncthreads_isa_evidence.txt): in a minimal kernel hipcc (ROCm 7.2) does put
+// s_waitcnt lgkmcnt(0) in front of the s_barrier of a __syncthreads(); in triangle_mfma_kernel, at the top-of-pass barrier,
+// it emits lgkmcnt(3) -- the LGKM counter is shared with scalar-memory loads, which return out of order, so three
+// outstanding operations do not prove that the older ds_write has completed.  The explicit wait is what the fix rests
+// on; it costs nothing measurable.  Every barrier in these sources goes through here.
 __device__ __forceinline__ void block_sync()
 {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
