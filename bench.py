@@ -81,6 +81,9 @@ def parse(argv=None):
                     help="kernel behind ld_triangle (auto = the FP4 MFMA kernel; results are identical)")
     ap.add_argument("--deadline", type=float, default=1500.0, help="seconds the launcher waits for the rank processes")
     ap.add_argument("--pg-timeout", type=float, default=300.0, help="seconds a collective may take before the job aborts")
+    ap.add_argument("--debug-corrupt-result", action="store_true",
+                    help="test hook: rank 0 flips one result cell before the check of the timed region (the run must then "
+                         "end with exit code 97, unretried: tests/test_gpu_dist.py)")
     ap.add_argument("--no-single-gpu-leg", action="store_true",
                     help="N > 1: skip timing the whole workload on rank 0 alone (the strong-scaling reference)")
     return ap.parse_args(argv)
@@ -94,6 +97,8 @@ def _free_port() -> int:
 
 
 RC_VERIFY = 97      # a rank's timed steps did not reproduce the triangle: a wrong RESULT, never retried, never hidden
+VERIFY_MARK = "BENCH_VERIFY_FAILED"   # ... and the line the rank prints on stdout: torch.distributed.run turns every worker
+                                      # failure into its own exit code 1, so the launcher recognises the case by this line
 RC_DEADLINE = 124   # the rank processes overran --deadline
 
 
@@ -144,7 +149,7 @@ def launch_ranks(args, argv) -> int:
     rc, out = attempt([])
     line = json_line(out)
     first_rc, retried = rc, False
-    if rc == RC_VERIFY:
+    if rc == RC_VERIFY or VERIFY_MARK in out:
         print("[bench] a rank's timed steps did not reproduce the triangle: NOT retried", file=sys.stderr)
         sys.stdout.write(out)
         return RC_VERIFY
@@ -505,9 +510,11 @@ def run_rank(args):
     # the output of the timed region against a separately computed result: nothing was skipped or left stale
     check = ld_triangle(panel, unit_range=(u0, u1), fmt=fmt)
     torch.cuda.synchronize()
+    if args.debug_corrupt_result and rank == 0:
+        out.cells.view(torch.int32).view(-1)[12345] ^= 1
     if not torch.equal(check.cells.view(torch.int32), out.cells.view(torch.int32)):
         print("bench.py: the timed steps did not reproduce the triangle (stale or skipped work)", file=sys.stderr, flush=True)
-        sys.stdout.flush()
+        print(f"{VERIFY_MARK} rank {rank}", flush=True)
         os._exit(RC_VERIFY)     # a distinct code the launcher propagates and never retries
     del check
 

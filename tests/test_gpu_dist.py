@@ -50,3 +50,19 @@ def test_bench_launches_its_own_ranks():
     assert rec["config"]["workload"] == "ld_triangle 3000x5008" and rec["value"] > 0
     assert rec["config"]["single_gpu_same_workload"]["pairs_per_s"] > 0
     assert rec["roofline"]["kernel_ms"] >= rec["roofline"]["kernel_ms_min_rank"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_never_retries_a_wrong_result():
+    """A rank whose timed steps do not reproduce the triangle ends the whole run with exit code 97: no second attempt, no
+    JSON line (a retry there would hide exactly the class of bug the check exists for).  The hook
+    --debug-corrupt-result flips one cell on rank 0 before the check."""
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--snps", "2000",
+                        "--backend", "gloo", "--settle-steps", "0", "--deadline", "400", "--no-single-gpu-leg",
+                        "--debug-corrupt-result"], capture_output=True, text=True, timeout=500, env=env, cwd=str(ROOT))
+    assert r.returncode == 97, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    assert not any(ln.startswith("{") and '"metric"' in ln for ln in r.stdout.splitlines())
+    assert "NOT retried" in r.stderr and "once more in the plainest mode" not in r.stderr
