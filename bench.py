@@ -81,6 +81,9 @@ def parse(argv=None):
                     help="kernel behind ld_triangle (auto = the FP4 MFMA kernel; results are identical)")
     ap.add_argument("--deadline", type=float, default=1500.0, help="seconds the launcher waits for the rank processes")
     ap.add_argument("--pg-timeout", type=float, default=300.0, help="seconds a collective may take before the job aborts")
+    ap.add_argument("--debug-hang", action="store_true",
+                    help="test hook: every rank sleeps instead of running (the launcher must end the whole process group at "
+                         "--deadline and return 124: tests/test_dist_gloo.py)")
     ap.add_argument("--debug-corrupt-result", action="store_true",
                     help="test hook: rank 0 flips one result cell before the check of the timed region (the run must then "
                          "end with exit code 97, unretried: tests/test_gpu_dist.py)")
@@ -353,6 +356,10 @@ def other_workloads(torch, dev, fmt, bench_codes):
 # ------------------------------------------------------------------------------------------ one rank
 def run_rank(args):
     import datetime
+
+    if args.debug_hang:          # before anything touches the GPU: the launcher's deadline handling is testable on any box
+        print(f"[bench] rank {os.environ.get('RANK', '0')} pid {os.getpid()} hangs on request", file=sys.stderr, flush=True)
+        time.sleep(3600)
 
     import torch
     import torch.distributed as dist

@@ -100,3 +100,30 @@ def test_bench_launcher_fails_loudly_without_gpu():
     assert r.returncode != 0
     assert '"metric"' not in r.stdout
     assert "needs a HIP device" in r.stderr and "once more in the plainest mode" in r.stderr
+
+
+def test_bench_launcher_ends_the_whole_process_group_at_the_deadline():
+    """on a --deadline overrun the launcher must end torch.distributed.run AND the rank grandchildren (they hold
+    the GPUs), return 124 and start nothing beside them.  The ranks hang on request (--debug-hang, before any GPU call, so
+    this runs on a box without a GPU); afterwards no process of the run is left."""
+    import re
+    import time
+
+    import psutil
+
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--snps", "300",
+                        "--backend", "gloo", "--deadline", "25", "--debug-hang"], capture_output=True, text=True, timeout=300,
+                       env=env, cwd=str(ROOT))
+    assert r.returncode == 124, (r.returncode, r.stderr[-2000:])
+    assert time.time() - t0 < 120
+    assert "ending their process group" in r.stderr and "once more in the plainest mode" not in r.stderr
+    pids = [int(x) for x in re.findall(r"pid (\d+) hangs on request", r.stderr)]
+    assert len(pids) == 2, r.stderr[-2000:]
+    time.sleep(1.0)
+    for pid in pids:
+        alive = psutil.pid_exists(pid) and psutil.Process(pid).status() != psutil.STATUS_ZOMBIE
+        assert not alive, f"rank process {pid} survived the launcher"
