@@ -165,6 +165,15 @@ def test_reference_import_lines_work_unchanged():
         "from backend.calc_ld import calc_ld\n"                               # ld_triangle.py:377, verbatim
         "from backend.get_sample_names import get_sample_names\n"             # ld_triangle.py:373
         "from backend.create_src_dict import create_src_dict\n"               # ld_triangle.py:374
+        "from backend.prep_intgen_data import prep_intgen_data\n"             # ld_triangle.py:372 (returns the prepared folder's db)
+        "import tempfile, os\n"
+        "d = tempfile.mkdtemp(); open(os.path.join(d, 'conversion.db'), 'w').close()\n"
+        "assert prep_intgen_data(d) == os.path.join(d, 'conversion.db')\n"
+        "try:\n"
+        "    prep_intgen_data(tempfile.mkdtemp())\n"
+        "    raise SystemExit('an unprepared folder must raise')\n"
+        "except FileNotFoundError:\n"
+        "    pass\n"
         "import ld_tools_amd.backend.calc_ld as impl, inspect\n"
         "assert calc_ld is impl.calc_ld\n"
         "assert list(inspect.signature(calc_ld).parameters) == ['var_1_genotypes', 'var_2_genotypes']\n"
