@@ -3,9 +3,10 @@
 
 Run in the build container only (needs /root/reference, which never travels):
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py [--out DIR]        (default: tests/golden/ itself)
 
-It imports the reference's ``backend/calc_ld.py`` (pure Python, no imports of its own) and
+It loads the reference's ``backend/calc_ld.py`` BY FILE PATH (tests/golden/_reference.py: this repo's own
+top-level ``backend/`` package would shadow it on sys.path; pure Python, no imports of its own) and
 records its outputs on inputs produced by this repo's own deterministic generator
 (ld_tools_amd/synth.py) or realised from count tuples.  Only inputs (or their seeds) and
 expected outputs are stored -- no reference source text.
@@ -28,11 +29,14 @@ import numpy as np
 
 HERE = Path(__file__).resolve().parent
 ROOT = HERE.parent.parent
+OUT = HERE                       # --out DIR redirects every file written (the regen-and-compare test)
 sys.dont_write_bytecode = True
-sys.path.insert(0, "/root/reference")
+sys.path.insert(0, str(HERE))
 sys.path.insert(0, str(ROOT))
 
-from backend.calc_ld import calc_ld as ref_calc_ld  # noqa: E402  (the reference)
+import _reference  # noqa: E402
+
+ref_calc_ld = _reference.load_reference_calc_ld()      # the reference, checked by code-object file name
 
 from ld_tools_amd import synth  # noqa: E402
 from oracle import ld_oracle as orc  # noqa: E402
@@ -124,7 +128,7 @@ def make_kat():
             errors.append({"g1": g1, "g2": g2, "raises": None})
         except Exception as exc:  # noqa: BLE001
             errors.append({"g1": g1, "g2": g2, "raises": type(exc).__name__})
-    (HERE / "kat_counts.json").write_text(json.dumps({"tuples": tuples, "literal": lit, "errors": errors}, indent=1))
+    (OUT / "kat_counts.json").write_text(json.dumps({"tuples": tuples, "literal": lit, "errors": errors}, indent=1))
     print("kat_counts.json:", len(tuples), "tuples,", len(lit), "literal,", len(errors), "errors")
 
 
@@ -168,7 +172,7 @@ def make_small_n():
         k_r[idx], k_d[idx] = kr, kd
         k_f1[idx], k_f2[idx] = enc(res["var_1_alt_freq"])[0], enc(res["var_2_alt_freq"])[0]
         flags[idx] = (orc.FLAG_DPRIME_INT0 if idp else 0) | (orc.FLAG_RSQ_INT0 if ir else 0)
-    np.savez_compressed(HERE / "small_n.npz", counts=arr, k_rsq=k_r, k_dp=k_d, k_f1=k_f1, k_f2=k_f2, flags=flags)
+    _reference.save_npz(OUT / "small_n.npz", counts=arr, k_rsq=k_r, k_dp=k_d, k_f1=k_f1, k_f2=k_f2, flags=flags)
     print("small_n.npz:", len(rows), "tuples")
 
 
@@ -225,7 +229,7 @@ def make_panels():
         out[name + ".k_freq"] = k_f
         out[name + ".sha256"] = np.frombuffer(hashlib.sha256(codes.tobytes()).digest(), dtype=np.uint8)
         print(name, "pairs", npair, "mean r2 k", k_r.mean())
-    np.savez_compressed(HERE / "panels.npz", **out)
+    _reference.save_npz(OUT / "panels.npz", **out)
 
 
 def make_drivers():
@@ -252,11 +256,14 @@ def make_drivers():
         area.append({"queries": queries, "flank": flank, "measure": measure, "thres": thres,
                      "hits": [list(h) for h in hits]})
         print("area", flank, measure, thres, "hits", len(hits))
-    (HERE / "drivers.json").write_text(json.dumps({"panel": "c1_64x5008", "positions": positions, "triangle": tri,
+    (OUT / "drivers.json").write_text(json.dumps({"panel": "c1_64x5008", "positions": positions, "triangle": tri,
                                                    "area": area}))
 
 
 if __name__ == "__main__":
+    if "--out" in sys.argv:
+        OUT = Path(sys.argv[sys.argv.index("--out") + 1])
+        OUT.mkdir(parents=True, exist_ok=True)
     make_kat()
     make_small_n()
     make_panels()

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Expected driver outputs (text) made with the REAL reference calc_ld -> tests/golden/driver_text.json.
 
-Run in the build container only (needs /root/reference):   python tests/golden/make_golden_drivers.py
+Run in the build container only (needs /root/reference):   python tests/golden/make_golden_drivers.py [--out DIR]
+The reference is loaded by file path (tests/golden/_reference.py), never through sys.path.
 The loops and writers are tests/ref_loops.py (a restatement); only calc_ld comes from the reference.  Stored:
 the texts, not the reference's source.
 """
@@ -12,11 +13,15 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 ROOT = HERE.parent.parent
 sys.dont_write_bytecode = True
-sys.path.insert(0, "/root/reference")
+sys.path.insert(0, str(HERE))
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
-from backend.calc_ld import calc_ld as ref_calc_ld  # noqa: E402  (the reference)
+import _reference  # noqa: E402
+
+ref_calc_ld = _reference.load_reference_calc_ld()      # the reference, checked by code-object file name
+OUT = Path(sys.argv[sys.argv.index("--out") + 1]) if "--out" in sys.argv else HERE
+OUT.mkdir(parents=True, exist_ok=True)
 
 import fakevcf  # noqa: E402
 import ref_loops  # noqa: E402
@@ -56,5 +61,5 @@ for ftype in ("tsv", "json"):
     for measure, thres, flank in (("r_square", 0.05, 900), ("d_prime", 0.9, 2500)):
         out["area_ragged"][f"{ftype}|{measure}|{thres}|{flank}"] = ref_loops.area_files(
             rvcf, "6", runiq[::4], rnames, flank, measure, thres, ftype, ("ALL",), ("male", "female"), ref_calc_ld)
-(HERE / "driver_text.json").write_text(json.dumps(out, indent=0, sort_keys=True))
+(OUT / "driver_text.json").write_text(json.dumps(out, indent=0, sort_keys=True))
 print({k: {kk: (len(v) if isinstance(v, str) else len(v)) for kk, v in d.items()} for k, d in out.items()})

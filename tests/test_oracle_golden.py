@@ -188,3 +188,38 @@ def test_oracles_area_driver(drivers, panel_codes):
         assert [(int(a), int(b)) for a, b in zip(hq, ho)] == [(w[0], w[1]) for w in want]
         assert np.array_equal(hr, np.array([w[3] for w in want], dtype=np.float64))
         assert np.array_equal(hd, np.array([w[4] for w in want], dtype=np.float64))
+
+
+# ------------------------------------------------------------------ the pin's own recipe
+REFERENCE_CALC_LD = "/root/reference/backend/calc_ld.py"
+GOLDEN_FILES = ("kat_counts.json", "small_n.npz", "panels.npz", "drivers.json", "driver_text.json")
+
+
+@pytest.mark.skipif(not __import__("os").path.isfile(REFERENCE_CALC_LD),
+                    reason="the reference exists in the build container only")
+def test_golden_generators_load_the_reference_and_reproduce_the_fixtures(tmp_path):
+    """Regenerate every fixture from the REAL reference into a temp dir and byte-compare with tests/golden/.
+
+    Guards against (i) the generators resolving ``backend.calc_ld`` to this repo's own top-level ``backend/``
+    package (the GPU drop-in) instead of /root/reference/backend/calc_ld.py:3-99 -- which would make the golden
+    vectors circular -- and (ii) committed fixtures that are not what the committed scripts produce.
+    """
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    golden = Path(__file__).resolve().parent / "golden"
+    sys.path.insert(0, str(golden))
+    try:
+        import _reference
+    finally:
+        sys.path.remove(str(golden))
+    fn = _reference.load_reference_calc_ld()
+    assert fn.__code__.co_filename == REFERENCE_CALC_LD
+    for script in ("make_golden.py", "make_golden_drivers.py"):
+        text = (golden / script).read_text()
+        assert "load_reference_calc_ld()" in text and "from backend" not in text, script
+        subprocess.run([sys.executable, str(golden / script), "--out", str(tmp_path)], check=True,
+                       stdout=subprocess.DEVNULL, timeout=600)
+    for name in GOLDEN_FILES:
+        assert (tmp_path / name).read_bytes() == (golden / name).read_bytes(), f"{name}: regen differs"
