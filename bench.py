@@ -87,6 +87,11 @@ def parse(argv=None):
     ap.add_argument("--debug-corrupt-result", action="store_true",
                     help="test hook: rank 0 flips one result cell before the check of the timed region (the run must then "
                          "end with exit code 97, unretried: tests/test_gpu_dist.py)")
+    ap.add_argument("--other-scale", default="full", choices=("full", "small"),
+                    help="tests: 'small' shrinks the other_workloads panels (6 000 x 1008, 12 000 x 5008)")
+    ap.add_argument("--debug-corrupt-other", action="store_true",
+                    help="test hook: one cell of the configs[4] leg of other_workloads is flipped before its check (the run "
+                         "must end with exit code 97 and no throughput line: tests/test_gpu_dist.py)")
     ap.add_argument("--no-single-gpu-leg", action="store_true",
                     help="N > 1: skip timing the whole workload on rank 0 alone (the strong-scaling reference)")
     return ap.parse_args(argv)
@@ -137,6 +142,10 @@ def launch_ranks(args, argv) -> int:
                     break
                 except subprocess.TimeoutExpired:
                     continue
+            try:        # torch.distributed.run may be gone while a rank grandchild (blocked in a driver call) is not:
+                os.killpg(proc.pid, signal.SIGKILL)     # the group, not the leader, is what must be gone
+            except ProcessLookupError:
+                pass
             try:
                 out, _ = proc.communicate(timeout=5.0)
             except Exception:                       # noqa: BLE001
@@ -240,20 +249,25 @@ def _cpu_model():
 
 
 # ------------------------------------------------------------------------------------------ other workloads (N = 1)
-def other_workloads(torch, dev, fmt, bench_codes):
-    """BASELINE.json configs[4] and configs[2] on the driver-run line, each a few launches at settled clocks and each
-    checked against a second, independently computed result; plus what SURVEY 8d asks to report beside pairs/s: the pack
-    kernel and the host-to-device copy of the bench panel's codes (never part of `value`)."""
-    from ld_tools_amd import PackedPanel, ld_area, ld_triangle, ops, synth
-    from ld_tools_amd._lib import lib
+def other_workloads(torch, dev, fmt, bench_codes, scale="full", corrupt=False):
+    """BASELINE.json configs[4], configs[3]'s panel on ONE GPU and configs[2] on the driver-run line, each a few launches
+    at settled clocks and each checked against a second, independently computed result (a mismatch ends the run with
+    RC_VERIFY, like a mismatch of the headline); plus what SURVEY 8d asks to report beside pairs/s: the pack kernel and
+    the host-to-device copy of the bench panel's codes (never part of `value`).  `scale` = "small" shrinks the three
+    panels (tests only; the keys then carry the sizes actually run)."""
+    from ld_tools_amd import PackedPanel, dist as ldist, ld_area, ld_triangle, ops, synth
+    from ld_tools_amd._lib import UNIT_PAIRS, lib
 
     def events():
         return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
+    small = scale != "full"
     res = {}
+    cell_bytes = 4 if fmt == "k16" else 8
     # ---- configs[4]: ld_triangle 50 000 x 1008 (EUR sub-panel), the HBM-write regime ----
+    n, h = (6000, 1008) if small else (50000, 1008)
+    key4 = f"ld_triangle {n}x{h}"
     try:
-        n, h = 50000, 1008
         p = PackedPanel.from_codes(synth.synth_codes_device(n, h, seed=synth.BENCH_SEED, device=dev))
         o = ld_triangle(p, fmt=fmt)
         for _ in range(3):
@@ -268,14 +282,15 @@ def other_workloads(torch, dev, fmt, bench_codes):
         c.record()
         torch.cuda.synchronize()
         ms = a.elapsed_time(c) / reps
+        if corrupt:                                              # test hook (--debug-corrupt-other)
+            o.cells.view(torch.int32).view(-1)[4321] ^= 1
         chk = ld_triangle(p, fmt=fmt, path="popcount")          # the independent kernel (AND + popcount, fp64 epilogue)
         torch.cuda.synchronize()
         same = bool(torch.equal(chk.cells.view(torch.int32), o.cells.view(torch.int32)))
         del chk
         pairs = n * (n - 1) // 2
-        cell_bytes = 4 if fmt == "k16" else 8
         alg = float(cell_bytes) * pairs + lib.ldx_plane_bytes(n, h)
-        res["ld_triangle 50000x1008"] = {
+        res[key4] = {
             "ms": ms, "pairs_per_s": pairs / (ms * 1e-3), "fmt": fmt, "verified_against": "popcount kernel, every cell",
             "results_equal": same,
             "roofline_hbm": {"bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -284,41 +299,97 @@ def other_workloads(torch, dev, fmt, bench_codes):
         del o, p
         torch.cuda.empty_cache()
     except Exception as exc:   # noqa: BLE001  (a reported extra, never a reason to lose the bench line)
-        res["ld_triangle 50000x1008"] = {"error": f"{type(exc).__name__}: {exc}"}
-    # ---- configs[2]: ld_area, 100 000 SNPs, +-500 kb, r2 >= 0.8, every SNP a query ----
+        res[key4] = {"error": f"{type(exc).__name__}: {exc}"}
+    # ---- the 100 000 x 5008 panel: configs[3]'s triangle on ONE GPU (the 1-GPU point of the strong-scaling series and
+    #      the panel the >= 40 % target is written for), then configs[2]'s ld_area on the same resident panel ----
+    n, h = (12000, 5008) if small else (100000, 5008)
+    key3, key2 = f"ld_triangle {n}x{h}", f"ld_area {n} +-500kb r2>=0.8"
+    p = None
     try:
-        n, h = 100000, 5008
         p = PackedPanel.from_codes(synth.synth_codes_device(n, h, seed=synth.BENCH_SEED, device=dev))
-        pos = torch.as_tensor(synth.synth_positions(n, step=500)).to(dev)
-        hits = ld_area(p, pos, None, 500000, "r_square", 0.8)
-        for _ in range(2):
-            ld_area(p, pos, None, 500000, "r_square", 0.8, check_positions=False)
-        torch.cuda.synchronize()
-        reps, ev, scan_ms = 5, [], 0.0
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            hits = ld_area(p, pos, None, 500000, "r_square", 0.8, check_positions=False, events=ev)
-            torch.cuda.synchronize()
-            scan_ms += ev[0].elapsed_time(ev[1])
-        wall = (time.perf_counter() - t0) / reps
-        old = ops.get_area_path()
-        try:
-            ops.set_area_path("popcount")                        # the independent scan kernel
-            ref = ld_area(p, pos, None, 500000, "r_square", 0.8, check_positions=False)
-        finally:
-            ops.set_area_path(old)
-        same = bool(len(ref) == len(hits) and torch.equal(ref.query, hits.query) and torch.equal(ref.oppos, hits.oppos)
-                    and torch.equal(ref.ld32.view(torch.int32), hits.ld32.view(torch.int32)))
-        n_pairs = hits.n_pairs
-        res["ld_area 100000 +-500kb r2>=0.8"] = {
-            "end_to_end_ms": wall * 1e3, "ordered_pairs": n_pairs, "ordered_pairs_per_s": n_pairs / wall, "hits": len(hits),
-            "scan_ms": scan_ms / reps, "scan": "ldx_area_dev: query mask, band plan, FP4 band kernel (HIP events)",
-            "end_to_end": "positions resident on the device; scan + count / offsets / scatter / order kernels + one host read",
-            "verified_against": "popcount scan, every hit in order", "results_equal": same}
-        del p, hits, ref
-        torch.cuda.empty_cache()
     except Exception as exc:   # noqa: BLE001
-        res["ld_area 100000 +-500kb r2>=0.8"] = {"error": f"{type(exc).__name__}: {exc}"}
+        res[key3] = res[key2] = {"error": f"{type(exc).__name__}: {exc}"}
+    if p is not None:
+        try:
+            o = ld_triangle(p, fmt=fmt)                              # 20 GB of 4-byte cells at 100 000 SNPs
+            ld_triangle(p, out=o, fmt=fmt)
+            torch.cuda.synchronize()
+            o.cells.fill_(-1)
+            reps, kms = 4, []
+            a, c = events()
+            a.record()
+            for _ in range(reps):
+                k0, k1 = events()
+                k0.record()
+                ld_triangle(p, out=o, fmt=fmt)
+                k1.record()
+                kms.append((k0, k1))
+            c.record()
+            torch.cuda.synchronize()
+            ms = a.elapsed_time(c) / reps
+            kern_ms = sum(x.elapsed_time(y) for x, y in kms) / reps
+            # verification: whole unit ranges of the eight-way partition, recomputed by the popcount kernel
+            parts = ldist.unit_partition(n, 8)
+            checked, same = [], True
+            for r in (2, 7):
+                u0, u1 = parts[r]
+                chk = ld_triangle(p, unit_range=(u0, u1), fmt=fmt, path="popcount")
+                torch.cuda.synchronize()
+                mine = o.cells.view(torch.int32)[u0 * UNIT_PAIRS:u1 * UNIT_PAIRS]
+                same = same and bool(torch.equal(chk.cells.view(torch.int32), mine))
+                checked.append(r)
+                del chk, mine
+            pairs = n * (n - 1) // 2
+            alg_ops = 2.0 * h * pairs
+            alg = float(cell_bytes) * pairs + lib.ldx_plane_bytes(n, h)
+            res[key3] = {
+                "ms": ms, "pairs_per_s": pairs / (ms * 1e-3), "fmt": fmt, "launches": reps,
+                "verified_against": f"popcount kernel, every cell of unit ranges {checked} of unit_partition({n}, 8)",
+                "results_equal": same,
+                "roofline": {"bound": "mfma", "achieved": alg_ops / (kern_ms * 1e-3) / 1e12, "peak": MFMA_FP4_PEAK_TOPS,
+                             "unit": "TOP/s", "frac": alg_ops / (kern_ms * 1e-3) / 1e12 / MFMA_FP4_PEAK_TOPS,
+                             "kernel": "triangle_mfma_kernel", "kernel_ms": kern_ms, "algorithmic_ops": alg_ops},
+                "roofline_hbm": {"bound": "hbm", "achieved": alg / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                 "unit": "GB/s", "frac": alg / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "algorithmic_bytes": alg}}
+            del o
+            torch.cuda.empty_cache()
+        except Exception as exc:   # noqa: BLE001
+            res[key3] = {"error": f"{type(exc).__name__}: {exc}"}
+            torch.cuda.empty_cache()
+        # ---- configs[2]: ld_area, 100 000 SNPs, +-500 kb, r2 >= 0.8, every SNP a query ----
+        try:
+            pos = torch.as_tensor(synth.synth_positions(n, step=500)).to(dev)
+            hits = ld_area(p, pos, None, 500000, "r_square", 0.8)
+            for _ in range(2):
+                ld_area(p, pos, None, 500000, "r_square", 0.8, check_positions=False)
+            torch.cuda.synchronize()
+            reps, ev, scan_ms = 5, [], 0.0
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                hits = ld_area(p, pos, None, 500000, "r_square", 0.8, check_positions=False, events=ev)
+                torch.cuda.synchronize()
+                scan_ms += ev[0].elapsed_time(ev[1])
+            wall = (time.perf_counter() - t0) / reps
+            old = ops.get_area_path()
+            try:
+                ops.set_area_path("popcount")                        # the independent scan kernel
+                ref = ld_area(p, pos, None, 500000, "r_square", 0.8, check_positions=False)
+            finally:
+                ops.set_area_path(old)
+            same = bool(len(ref) == len(hits) and torch.equal(ref.query, hits.query) and torch.equal(ref.oppos, hits.oppos)
+                        and torch.equal(ref.ld32.view(torch.int32), hits.ld32.view(torch.int32)))
+            n_pairs = hits.n_pairs
+            res[key2] = {
+                "end_to_end_ms": wall * 1e3, "ordered_pairs": n_pairs, "ordered_pairs_per_s": n_pairs / wall, "hits": len(hits),
+                "scan_ms": scan_ms / reps, "scan": "ldx_area_dev: query mask, band plan, FP4 band kernel (HIP events)",
+                "end_to_end": "positions resident on the device; scan + count / offsets / scatter / order kernels + one host read",
+                "verified_against": "popcount scan, every hit in order", "results_equal": same}
+            del hits, ref
+        except Exception as exc:   # noqa: BLE001
+            res[key2] = {"error": f"{type(exc).__name__}: {exc}"}
+        del p
+        torch.cuda.empty_cache()
     # ---- pack and host-to-device of the bench panel's codes (reported separately, not in pairs/s) ----
     try:
         ns, nh = bench_codes.shape
@@ -696,7 +767,15 @@ def run_rank(args):
         except Exception as exc:   # noqa: BLE001  (an extra)
             line["other_paths"]["two_streams"] = {"error": f"{type(exc).__name__}: {exc}"}
     if world == 1 and not use_dist and not args.no_other_workloads:
-        line["other_workloads"] = other_workloads(torch, dev, fmt, codes_local)
+        line["other_workloads"] = other_workloads(torch, dev, fmt, codes_local, args.other_scale, args.debug_corrupt_other)
+    # every extra leg that compares two results is held to the headline's rule: a mismatch is a wrong RESULT -- no
+    # throughput line, exit code RC_VERIFY
+    bad = [k for grp in ("other_paths", "other_workloads") for k, v in line.get(grp, {}).items()
+           if isinstance(v, dict) and v.get("results_equal") is False]
+    if bad:
+        print(f"bench.py: {bad} did not reproduce the independently computed result", file=sys.stderr, flush=True)
+        print(f"{VERIFY_MARK} rank {rank} {bad}", flush=True)
+        os._exit(RC_VERIFY)
     if world > 1 and not args.no_single_gpu_leg:
         # strong-scaling reference: the WHOLE workload on rank 0's GPU alone, a few steps (the other ranks wait)
         single = None

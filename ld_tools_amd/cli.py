@@ -73,11 +73,11 @@ def triangle_parser():
                        formatter_class=RawTextHelpFormatter)
     _common(p)
     p.add_argument("-l", "--ld-measure", metavar="[r_square]", choices=["r_square", "d_prime"], default="r_square",
-                   dest="ld_measure", type=str, help=_t("{r_square, d_prime} LD measure for building matrices and for the lower threshold", "{r_square, d_prime} Мера LD для матриц и для нижнего порога"))
+                   dest="ld_measure", type=str, help=_t("{r_square, d_prime} Which LD statistic fills the matrices (the -z cut-off applies to it too)", "{r_square, d_prime} Мера LD для матриц и для нижнего порога"))
     p.add_argument("-z", "--ld-low-thres", metavar="[None]", dest="ld_low_thres", type=float,
-                   help=_t("Lower LD threshold (subthreshold values will be zeroed)", "Нижний порог LD (значения ниже порога заменяются нулём)"))
+                   help=_t("Cut-off: matrix cells whose LD lies under it are written as 0", "Нижний порог LD (значения ниже порога заменяются нулём)"))
     p.add_argument("-o", "--matrix-type", metavar="[heatmap]", choices=["heatmap", "table", "both"], default="heatmap",
-                   dest="matrix_type", type=str, help=_t("{heatmap, table, both} Type of LD value matrices (this build writes the table)", "{heatmap, table, both} Вид матриц LD (эта сборка пишет таблицу)"))
+                   dest="matrix_type", type=str, help=_t("{heatmap, table, both} Output kind; this build writes the tab-separated table for every choice (no plotly heat map) and says so on stderr", "{heatmap, table, both} Вид матриц LD (эта сборка пишет таблицу)"))
     p.add_argument("-j", "--heatmap-json", dest="heatmap_json", action="store_true", help=_t("(heat maps are not produced by this build)", "(тепловые карты эта сборка не строит)"))
     p.add_argument("-i", "--disp-letters", dest="disp_letters", action="store_true", help=_t("(heat maps are not produced by this build)", "(тепловые карты эта сборка не строит)"))
     p.add_argument("-c", "--color-pal", metavar="[greens]", default="greens", dest="color_pal", type=str, help=_t("(heat maps are not produced by this build)", "(тепловые карты эта сборка не строит)"))
@@ -95,13 +95,13 @@ def area_parser():
                        formatter_class=RawTextHelpFormatter)
     _common(p)
     p.add_argument("-w", "--flank-size", metavar="[100000]", default=100000, dest="flank_size", type=int,
-                   help=_t("Size of each flank around each query variant within which LD is calculated", "Размер каждого фланка вокруг запрашиваемого варианта, в пределах которого считается LD"))
+                   help=_t("Half-width, in bp, of the window around every query variant that is searched for linked variants", "Размер каждого фланка вокруг запрашиваемого варианта, в пределах которого считается LD"))
     p.add_argument("-l", "--ld-thres-measure", metavar="[r_square]", choices=["r_square", "d_prime"], default="r_square",
-                   dest="ld_thres_measure", type=str, help=_t("{r_square, d_prime} LD measure for setting the lower threshold", "{r_square, d_prime} Мера LD, по которой задаётся нижний порог"))
+                   dest="ld_thres_measure", type=str, help=_t("{r_square, d_prime} Which LD statistic the -z cut-off is compared with", "{r_square, d_prime} Мера LD, по которой задаётся нижний порог"))
     p.add_argument("-z", "--ld-low-thres", metavar="[0.8]", default=0.8, dest="ld_low_thres", type=float,
-                   help=_t("Lower LD threshold", "Нижний порог LD"))
+                   help=_t("Keep an opposing variant only when its LD with the query reaches this value", "Оставлять вариант, только если его LD с запрашиваемым не ниже этого значения"))
     p.add_argument("-o", "--trg-file-type", metavar="[tsv]", choices=["tsv", "json", "rsids"], default="tsv",
-                   dest="trg_file_type", type=str, help=_t("{tsv, json, rsids} Format of target files", "{tsv, json, rsids} Формат выходных файлов"))
+                   dest="trg_file_type", type=str, help=_t("{tsv, json, rsids} How the result files are written", "{tsv, json, rsids} Формат выходных файлов"))
     p.add_argument("-p", "--max-proc-quan", metavar="[4]", default=4, dest="max_proc_quan", type=int,
                    help=_t("Maximum number of tables to be processed in parallel (worker threads of this process, one HIP stream each)", "Сколько таблиц обрабатывать одновременно (рабочие потоки этого процесса, у каждого свой HIP-поток)"))
     return p
@@ -110,8 +110,8 @@ def area_parser():
 def lite_parser():
     """cli/ld_lite_cli_en.py:37-49"""
     p = ArgumentParser(description=_t("Prints LD of a pair of variants.", "Выводит LD пары вариантов.") + f" Version: {__version__}", formatter_class=RawTextHelpFormatter)
-    p.add_argument("rs_id_1", metavar="rs_id_1", type=str, help=_t("Reference SNP ID of the first variant", "rsID первого варианта"))
-    p.add_argument("rs_id_2", metavar="rs_id_2", type=str, help=_t("Reference SNP ID of the second variant", "rsID второго варианта"))
+    p.add_argument("rs_id_1", metavar="rs_id_1", type=str, help=_t("rsID of one variant of the pair", "rsID первого варианта"))
+    p.add_argument("rs_id_2", metavar="rs_id_2", type=str, help=_t("rsID of the other variant of the pair", "rsID второго варианта"))
     _common(p, with_src=False)
     return p
 
@@ -211,6 +211,9 @@ def ld_triangle_main(argv=None):
     src_dir_path, trg_top, src_file_names = _src_files(args)
     opener = _vcf_opener(intgen_dir_path)
     proc_quan = _proc_quan(args.max_proc_quan, len(src_file_names))
+    if args.matrix_type != "table":     # the reference's default is the plotly heat map (ld_triangle.py:239-340): not built here
+        print(f"ld_triangle: -o {args.matrix_type}: heat maps are not produced by this build; writing the tab-separated "
+              "table instead (-o table silences this note)", file=sys.stderr)
     print(f"\nLD matrices building\n\tquantity of parallel workers (threads, one HIP stream each): {proc_quan}")
     t0 = datetime.datetime.now()
 

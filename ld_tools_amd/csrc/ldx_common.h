@@ -20,11 +20,11 @@ void set_error(const char *fmt, ...);
 // Workgroup barrier that first drains THIS wave's LDS traffic.  Symptom it removes: about once in 10^6 barriers a
 // ds_write issued just before the barrier (the pass ticket, by wave 0) was not yet visible to the ds_read another wave
 // issued right behind it -- that wave then redid an old pass and left its own undone (tools/gpu_soak.py).
-// ISA evidence (profiles/r03/syncthreads_isa_evidence.txt): in a minimal kernel hipcc (ROCm 7.2) does put
-// s_waitcnt lgkmcnt(0) in front of the s_barrier of a __syncthreads(); in triangle_mfma_kernel, at the top-of-pass barrier,
-// it emits lgkmcnt(3) -- the LGKM counter is shared with scalar-memory loads, which return out of order, so three
-// outstanding operations do not prove that the older ds_write has completed.  The explicit wait is what the fix rests
-// on; it costs nothing measurable.  Every barrier in these sources goes through here.
+// This is an EMPIRICAL fix: with it the symptom has not recurred in 6 100+ soak launches; the mechanism is unproven.
+// (profiles/r03/syncthreads_isa_evidence.txt shows that hipcc puts s_waitcnt lgkmcnt(3), not 0, in front of the
+// top-of-pass s_barrier of triangle_mfma_kernel; a non-zero count normally still covers the older ds_write, so that
+// listing is context, not a root cause.)  The explicit wait costs nothing measurable.  Every barrier in these sources
+// goes through here.
 __device__ __forceinline__ void block_sync()
 {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

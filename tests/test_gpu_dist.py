@@ -66,3 +66,40 @@ def test_bench_never_retries_a_wrong_result():
     assert r.returncode == 97, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
     assert not any(ln.startswith("{") and '"metric"' in ln for ln in r.stdout.splitlines())
     assert "NOT retried" in r.stderr and "once more in the plainest mode" not in r.stderr
+
+
+def _bench_n1(extra):
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    return subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "3", "--warmup", "1", "--snps", "2000",
+                           "--settle-steps", "0", "--no-cpu-baseline", "--other-scale", "small"] + extra,
+                          capture_output=True, text=True, timeout=500, env=env, cwd=str(ROOT))
+
+
+@pytest.mark.gpu
+def test_bench_other_workloads_are_verified():
+    """The N = 1 line's extra legs (configs[4] triangle, the configs[3] panel on one GPU, configs[2] ld_area, two streams)
+    each compare their timed result with an independently computed one; the line must say they agreed."""
+    import json
+
+    r = _bench_n1([])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    legs = rec["other_workloads"]
+    for key in ("ld_triangle 6000x1008", "ld_triangle 12000x5008", "ld_area 12000 +-500kb r2>=0.8"):
+        assert "error" not in legs[key], legs[key]
+        assert legs[key]["results_equal"] is True, (key, legs[key])
+    assert legs["ld_triangle 12000x5008"]["roofline"]["kernel_ms"] > 0
+    assert "unit ranges [2, 7]" in legs["ld_triangle 12000x5008"]["verified_against"]
+    assert rec["other_paths"]["two_streams"]["results_equal"] is True
+
+
+@pytest.mark.gpu
+def test_bench_a_wrong_extra_leg_is_a_failed_run():
+    """a mismatch in an extra leg used to publish its throughput with exit code 0.  Now it ends the run like
+    a mismatch of the headline: exit code 97, the marker line, no JSON line."""
+    r = _bench_n1(["--debug-corrupt-other"])
+    assert r.returncode == 97, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    assert "BENCH_VERIFY_FAILED" in r.stdout and "ld_triangle 6000x1008" in r.stdout
+    assert not any(ln.startswith("{") and '"metric"' in ln for ln in r.stdout.splitlines())

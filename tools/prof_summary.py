@@ -22,12 +22,42 @@ for f, r in rows("trace/**/*kernel_stats.csv"):
     seen = True
     print(f"{r.get('Name', '')[:70]:70s} calls={r.get('Calls')} total_ns={r.get('TotalDurationNs')} "
           f"avg_ns={r.get('AverageNs')} pct={r.get('Percentage')}")
-if not seen:
-    dur = defaultdict(list)
-    for f, r in rows("trace/**/*kernel_trace.csv"):
-        dur[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-    for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
-        print(f"{k[:70]:70s} calls={len(v)} total_ns={sum(v)} avg_ns={sum(v) / len(v):.0f}")
+
+# Per-launch durations from the kernel trace: the --stats average mixes cold / eager warm-up launches with the steady
+# state (its mean exceeded the bench's own ms_per_step).  Beside mean / median / min of ALL launches of a
+# kernel, "steady" = the launches of its longest back-to-back run (next start within 50 us of the previous end: the
+# graph replays of bench.py's settle + timed region, or a long eager loop), first tenth dropped (clock settling).
+launches = defaultdict(list)
+for f, r in rows("trace/**/*kernel_trace.csv"):
+    launches[r["Kernel_Name"]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+
+
+def med(v):
+    v = sorted(v)
+    return v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
+
+
+steady_json = {}
+if launches:
+    print("== per-launch durations from the kernel trace (ns) ==")
+    for name, iv in sorted(launches.items(), key=lambda kv: -sum(e - b for b, e in kv[1])):
+        iv.sort()
+        d = [e - b for b, e in iv]
+        line = (f"{name[:70]:70s} n={len(d)} mean={sum(d) / len(d):.0f} median={med(d):.0f} min={min(d)} max={max(d)}")
+        best, cur = [], [0]
+        for k in range(1, len(iv)):
+            if iv[k][0] - iv[k - 1][1] <= 50000:
+                cur.append(k)
+            else:
+                best, cur = (cur if len(cur) > len(best) else best), [k]
+        best = cur if len(cur) > len(best) else best
+        if len(best) >= 10:
+            run = [d[k] for k in best[len(best) // 10:]]
+            line += f" | steady run of {len(best)}: mean={sum(run) / len(run):.0f} median={med(run):.0f} min={min(run)}"
+            steady_json[name] = {"launches": len(d), "mean_ns": sum(d) / len(d), "median_ns": med(d), "min_ns": min(d),
+                                 "steady_run": len(best), "steady_mean_ns": sum(run) / len(run), "steady_median_ns": med(run)}
+        if not seen or "triangle" in name or "area" in name or "pack" in name:
+            print(line)
 
 for tag in ("pmc_fetch", "pmc_write", "pmc_sq"):
     acc = defaultdict(lambda: defaultdict(list))
@@ -71,3 +101,6 @@ for needle in ("triangle_mfma_kernel", "triangle_kernel"):
         with open(os.path.join(root, "traffic_counters.json"), "w") as fh:
             json.dump(rec, fh)
         break
+if steady_json:
+    with open(os.path.join(root, "launch_durations.json"), "w") as fh:
+        json.dump(steady_json, fh, indent=1)

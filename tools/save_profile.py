@@ -29,6 +29,8 @@ for line in open(src / "bench_trace.log"):
         (dst / f"{tag}_bench_under_rocprof.json").write_text(line)
 if (src / "command.txt").exists():
     shutil.copy(src / "command.txt", dst / f"{tag}_command.txt")
+if (src / "launch_durations.json").exists():    # per-launch mean / median / min and the steady back-to-back run (prof_summary.py)
+    shutil.copy(src / "launch_durations.json", dst / f"{tag}_launch_durations.json")
 if (src / "traffic_counters.json").exists():
     rec = json.loads((src / "traffic_counters.json").read_text())
     sys.path.insert(0, str(root))
