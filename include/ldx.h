@@ -39,16 +39,27 @@
 extern "C" {
 #endif
 
-#define LDX_VERSION 100            /* 0.1.0 */
+#define LDX_VERSION 101            /* 0.1.1: cell order inside a unit, ldx_triangle_cell_index takes the format */
 #define LDX_SLAB_ROWS 128u         /* SNP rows per slab == SNP columns per j-tile */
 #define LDX_GROUP_ROWS 8u          /* SNP rows a wavefront pairs against one j-tile per unit */
 #define LDX_CHUNK_HAPS 128u        /* haplotypes per 16-byte chunk */
 #define LDX_UNIT_PAIRS (LDX_SLAB_ROWS * LDX_GROUP_ROWS)   /* 1024 result cells per unit */
-/* Cell order INSIDE a unit (8 rows x 128 columns): row-major, r8 = row % 8, c = column % 128.  Every producer and consumer
- * of strip output goes through this macro (ld_tools_amd/_lib.py: cell_offset).  A column-quad-major order (32 quads of
- * 8 rows x 4 columns, which lets the matrix kernel write 16 bytes per lane in whole 128-byte lines once its operand roles are
- * swapped) was built and measured in round 3: slower on every shape (profiles/r03/quad_major_layout_ab.log). */
-#define LDX_CELL_OFFSET(r8, c) ((r8) * LDX_SLAB_ROWS + (c))
+/* Cell order INSIDE a unit (8 rows x 128 columns), r8 = row % 8, c = column % 128: rows one after the other (128 cells
+ * each).  Inside a row the order follows what ONE lane of the matrix kernel holds -- a 32 x 32 MFMA tile puts column l
+ * of each of the four column tiles into lane l, i.e. the four columns {c0, c0 + 32, c0 + 64, c0 + 96} -- so that the lane
+ * writes them with 16-byte stores and a wave's store instruction covers whole contiguous runs:
+ *   4-byte cells (ldx_k16):  the lane's four cells are adjacent: element 4 * (c % 32) + c / 32  (one store per row);
+ *   8-byte cells (ldx_ld32): the lane's cells of column tiles (0, 1) and (2, 3) are adjacent pairs:
+ *                            element 64 * (c / 64) + 2 * (c % 32) + (c / 32) % 2              (two stores per row).
+ * Why: the kernel's result stream was bound by the number of store INSTRUCTIONS a CU can issue, not by bytes (round 4:
+ * no stores at all -19 % kernel time at 50 000 x 1008, eight 4-byte stores -> two 16-byte stores per step -12 %;
+ * tools/probes/wrbw.hip, profiles/r04/store_issue_*.log).  Side outputs of a launch (n11, unrounded values) use the order
+ * of that launch's cell format.  Every producer and consumer of strip output goes through these macros
+ * (ld_tools_amd/_lib.py: cell_offset).  Round 3's column-quad-major attempt (quads of ADJACENT columns, which needed the
+ * MFMA operand roles swapped) was slower; this order needs no change to the arithmetic. */
+#define LDX_CELL_OFFSET4(r8, c) ((r8) * LDX_SLAB_ROWS + (((c) & 31u) << 2) + ((c) >> 5))
+#define LDX_CELL_OFFSET8(r8, c) ((r8) * LDX_SLAB_ROWS + (((c) >> 6) << 6) + (((c) & 31u) << 1) + (((c) >> 5) & 1u))
+#define LDX_CELL_OFFSET(out_format, r8, c) ((out_format) == LDX_OUT_K16 ? LDX_CELL_OFFSET4(r8, c) : LDX_CELL_OFFSET8(r8, c))
 #define LDX_MAX_HAPS 10240u        /* one j-tile (128 rows, all chunks) must fit 160 KiB of LDS */
 
 /* error codes */
@@ -107,12 +118,12 @@ size_t ldx_plane_bytes(uint32_t n_snps, uint32_t n_hap);   /* bytes of one tiled
 uint32_t ldx_padded_snps(uint32_t n_snps);                 /* n_slabs * 128 */
 /* Triangle work units.  Unit u of the strict lower triangle pairs the 8 rows of group g with the
  * 128 columns of j-tile t, u = t*G - 8*t*(t-1) + (g - 16*t), G = padded_snps/8, g >= 16*t.  Result
- * cell (row i, column j), i > j, lives at element u*1024 + LDX_CELL_OFFSET(i % 8, j % 128) of the strip
+ * cell (row i, column j), i > j, lives at element u*1024 + LDX_CELL_OFFSET(format, i % 8, j % 128) of the strip
  * output, t = j/128, g = i/8 (ldx_triangle_cell_index does the arithmetic). */
 uint64_t ldx_triangle_units(uint32_t n_snps);
 uint64_t ldx_triangle_unit_of(uint32_t n_snps, uint32_t row, uint32_t col);  /* requires row > col */
 uint64_t ldx_triangle_tile_base(uint32_t n_snps, uint32_t tile);             /* first unit of j-tile */
-uint64_t ldx_triangle_cell_index(uint32_t n_snps, uint32_t row, uint32_t col); /* element of cell (row > col) in the full strip output */
+uint64_t ldx_triangle_cell_index(uint32_t n_snps, uint32_t row, uint32_t col, int out_format); /* element of cell (row > col) in the full strip output of that cell format (LDX_OUT_*) */
 
 /* ---- packing: the genotype lists of ld_triangle.py:160-186 / ld_area.py:182-187,230-235 ---- */
 /* codes: int8 [n_snps][ld_codes], 1 = ALT, 0 = REF, anything else = neither (None, 2nd ALT...).

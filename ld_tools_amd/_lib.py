@@ -20,10 +20,15 @@ GROUP_ROWS = 8
 UNIT_PAIRS = SLAB_ROWS * GROUP_ROWS
 
 
-def cell_offset(r8, c):
-    """LDX_CELL_OFFSET of include/ldx.h: element of cell (row % 8, column % 128) inside its unit (row-major).  Works on
-    ints and numpy arrays."""
-    return r8 * SLAB_ROWS + c
+def cell_offset(r8, c, fmt="k16"):
+    """LDX_CELL_OFFSET of include/ldx.h: element of cell (row % 8, column % 128) inside its unit, in the order of the cell
+    format: rows one after the other; inside a row the columns {c0, c0 + 32, c0 + 64, c0 + 96} one lane of the matrix kernel
+    holds are adjacent (k16: all four; ld32: in two pairs).  Works on ints and numpy arrays."""
+    if fmt == "k16":
+        return r8 * SLAB_ROWS + ((c & 31) << 2) + (c >> 5)
+    if fmt != "ld32":
+        raise ValueError(f"unknown cell format {fmt!r}")
+    return r8 * SLAB_ROWS + ((c >> 6) << 6) + ((c & 31) << 1) + ((c >> 5) & 1)
 
 
 MAX_HAPS = 10240
@@ -94,7 +99,7 @@ SIGNATURES = {
     "ldx_triangle_units": (_u64, [_u32]),
     "ldx_triangle_unit_of": (_u64, [_u32, _u32, _u32]),
     "ldx_triangle_tile_base": (_u64, [_u32, _u32]),
-    "ldx_triangle_cell_index": (_u64, [_u32, _u32, _u32]),
+    "ldx_triangle_cell_index": (_u64, [_u32, _u32, _u32, C.c_int]),
     "ldx_pack_codes_dev": (_int, [_vp, _u32, _u32, _sz, _vp, _vp, _vp, _vp, _vp]),
     "ldx_tile_plane_dev": (_int, [_vp, _u32, _u32, _sz, _vp, _vp, _vp]),
     "ldx_snp_stats_dev": (_int, [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp]),

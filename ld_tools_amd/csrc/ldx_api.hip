@@ -101,9 +101,9 @@ extern "C" uint64_t ldx_triangle_unit_of(uint32_t n_snps, uint32_t row, uint32_t
     return tile_base(t, T * kGroupsPerSlab) + (g - t * kGroupsPerSlab);
 }
 
-extern "C" uint64_t ldx_triangle_cell_index(uint32_t n_snps, uint32_t row, uint32_t col)
+extern "C" uint64_t ldx_triangle_cell_index(uint32_t n_snps, uint32_t row, uint32_t col, int out_format)
 {
-    return ldx_triangle_unit_of(n_snps, row, col) * LDX_UNIT_PAIRS + LDX_CELL_OFFSET(row % kGroup, col % kSlab);
+    return ldx_triangle_unit_of(n_snps, row, col) * LDX_UNIT_PAIRS + LDX_CELL_OFFSET(out_format, row % kGroup, col % kSlab);
 }
 
 // ---- calc_ld for one pair, host pointers (used by the backend/calc_ld.py drop-in; ld_lite.py:143) ----

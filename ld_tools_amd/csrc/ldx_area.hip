@@ -517,9 +517,13 @@ extern "C" int ldx_area_dev(const void *alt, const double *fa, const double *fr,
     hipStream_t s = (hipStream_t)stream;
     const int path = g_area_path.load(std::memory_order_relaxed);
     if (path == LDX_PATH_MFMA || path == LDX_PATH_FP4 ||
-        (path == LDX_PATH_AUTO && (uint64_t)n_query * 16u >= n_snps && n_snps >= 2))
-        return area_mfma(alt, fa, fr, q, n_snps, n_hap, positions, queries, n_query, flank, measure, thres, hits, hit_cap,
-                         n_hits, workspace, path != LDX_PATH_MFMA, s);
+        (path == LDX_PATH_AUTO && (uint64_t)n_query * 16u >= n_snps && n_snps >= 2)) {
+        const int rc = area_mfma(alt, fa, fr, q, n_snps, n_hap, positions, queries, n_query, flank, measure, thres, hits, hit_cap,
+                                 n_hits, workspace, path != LDX_PATH_MFMA, s);
+        if (rc != ldx::kNoSlot) return rc;
+        if (path != LDX_PATH_AUTO) return LDX_E_UNSUPPORTED;
+        // AUTO and no ticket-counter slot for this stream: the popcount scan below finds the very same hits
+    }
     const uint32_t qpad = ldx_padded_snps(n_query), T = ldx::n_slabs(n_snps), nch = ldx::n_chunks(n_hap);
     LDX_HIP(hipMemsetAsync(n_hits, 0, sizeof(uint64_t), s));
     area_gather_kernel<<<(qpad + 3u) / 4u, 256, 0, s>>>((const uint4 *)alt, fa, fr, q, positions, queries, n_query, qpad,

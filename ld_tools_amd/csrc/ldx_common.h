@@ -35,6 +35,11 @@ __device__ __forceinline__ void block_sync()
 // ld_triangle.py:224) becomes the exact integer test k >= thres_to_k(thres).
 double thres_to_k(double thres);
 
+// internal return code of the two matrix-pipe entries below: no ticket-counter slot could be had for the stream (all 256 of
+// the device in flight or captured).  LDX_PATH_AUTO callers fall back to the popcount kernels, explicit paths report
+// LDX_E_UNSUPPORTED (the message is set).
+constexpr int kNoSlot = -1000;
+
 // ld_triangle on the matrix cores (ldx_mfma.hip); same contract as ldx_triangle_dev after argument checks
 int triangle_mfma(const void *alt, const double *fa, const double *fr, const double *q, uint32_t n_snps, uint32_t n_hap,
                   uint64_t unit_begin, uint64_t unit_end, int out_format, void *out, ldx_ld64 *out_raw, uint32_t *out_n11,
@@ -150,6 +155,14 @@ __device__ __forceinline__ ldx_k16 encode_cell<ldx_k16>(double kr, double kd, bo
     o.r_square = r_int0 ? (uint16_t)LDX_K16_INT0 : (kr < 32767.0 ? (uint16_t)(uint32_t)kr : (uint16_t)LDX_K16_BIG);
     o.d_prime = d_int0 ? (uint16_t)LDX_K16_INT0 : (kd < 32767.0 ? (uint16_t)(uint32_t)kd : (uint16_t)LDX_K16_BIG);
     return o;
+}
+
+// element of cell (row % 8, column % 128) inside its unit, in the order of the cell format (include/ldx.h)
+template <typename Cell>
+__host__ __device__ __forceinline__ uint32_t cell_offset(uint32_t r8, uint32_t c)
+{
+    if constexpr (sizeof(Cell) == 4) return LDX_CELL_OFFSET4(r8, c);
+    else return LDX_CELL_OFFSET8(r8, c);
 }
 
 template <typename Cell>
@@ -366,7 +379,11 @@ __device__ __forceinline__ void ld_multi_fast2(const T (&cnt_scaled)[W], const F
 // -- with a margin test that is wide enough for float32: a lane whose 8 pairs of a step are not ALL provably rounded
 // like the reference hands that step to the fp64 tier above (ld_multi_fast2), through a per-wave queue in LDS, so
 // the common path never branches per pair.  Valid only for ordinary SNPs on both sides (polymorphic, a + r == n:
-// then r^2 <= 1, D' <= 1, B >= 1 and a r >= n - 1, which the error bounds below use).
+// then r^2 <= 1, D' <= 1, B >= 1 and a r >= n - 1, which the error bounds below use); every other SNP parks (f32_row).
+// Round 4 built and measured a leaner form of this arithmetic (integer Dn from accumulators that start at 2^23, floor /
+// fract instead of the magic-number rounding, per-step instead of per-value margins: 22 instead of 28 VALU per pair, 25 %
+// faster stand-alone) -- and it was NOT faster inside the kernel (it parks 0.81 % instead of 0.59 % of the lane-steps, and
+// the step was bound by its store instructions, not its arithmetic): tools/probes/epi.hip, profiles/r04/fp32_tier_*.log.
 //
 // Error budget (u = 2^-24; every table entry is a double-precision value rounded once to float32):
 //   Dn = n c - a1 a2 is computed exactly while |Dn| < 2^24 (p = fl(a1 a2), e = a1 a2 - p exactly by fma,
@@ -400,14 +417,21 @@ __host__ __device__ inline F32Const f32_const(double n)
     return c;
 }
 
-// from the fp64 tier's per-SNP operands (a, 1/a, 1/r as doubles: errors ~1e-16, far below float32's u)
-__device__ __forceinline__ F32Row f32_row(double a, double ra, double rr)
+// from the fp64 tier's per-SNP operands (a, 1/a, 1/r as doubles: errors ~1e-16, far below float32's u).
+// A SNP that is not ordinary (monomorphic, or with missing codes: a + r < n) gets all-zero entries: every y_d it takes
+// part in is then exactly 0, the step's  min y_d > 0  test fails and the lane parks the step for the fp64 tier -- the
+// GENERAL variant of it, which knows degenerate operands.  So one such SNP costs its own row / column of cells the slow
+// path, not the whole unit (round 3: one monomorphic SNP among a tile's 128 columns sent every unit of the tile through
+// the fp64 epilogue -- 13 % of the units of the 50 000 x 1008 bench panel for 0.07 % such SNPs).
+__device__ __forceinline__ F32Row f32_row(double a, double ra, double rr, bool ordinary)
 {
+    if (!ordinary) return F32Row{0.0f, 0.0f, 0.0f, 0.0f};
     return F32Row{(float)a, (float)(1e4 * ra), (float)(1e4 * rr), (float)(10.0 * __builtin_sqrt(ra * rr))};
 }
 
-__device__ __forceinline__ F32Col f32_col(double a, double ra, double rr)
+__device__ __forceinline__ F32Col f32_col(double a, double ra, double rr, bool ordinary)
 {
+    if (!ordinary) return F32Col{0.0f, 0.0f, 0.0f, 0.0f};
     return F32Col{(float)a, (float)ra, (float)rr, (float)(10.0 * __builtin_sqrt(ra * rr))};
 }
 

@@ -72,7 +72,10 @@ constexpr uint32_t kRows64 = 64;              // i-rows per wave unit
 constexpr uint32_t kBRow = 144;               // bytes per expanded j-row in LDS (128 + 16 pad)
 constexpr uint32_t kBBuf = kSlab * kBRow;     // one buffer: 18 KiB (int8 image; the FP4 image [4 steps][2 halves][128 rows][16 B] is 16 KiB)
 constexpr uint32_t kStat = 6;                  // doubles per SNP in the LDS operand tables (16-byte aligned rows)
-[[maybe_unused]] constexpr uint32_t kStampPasses = 40, kStampStride = 6 + 4 * kStampPasses;   // tuning builds: LDX_STAMP
+// tuning builds: LDX_STAMP.  -DLDX_STAMPS_ONLY (with -DLDX_TUNING) keeps the stamps but compiles `ablate` to 0 and the event
+// counters out, so that the stamped code is the product's; the last 20 words of a wave's record then hold s_memtime at the
+// top of each of the sixteen fp32-tier steps of its SECOND pass and at the end of the loop.
+[[maybe_unused]] constexpr uint32_t kStampPasses = 40, kStampStride = 6 + 4 * kStampPasses + 20;
 
 // Bits to int8 operands.  The matrix pipe only needs A[k] * B[k] to be the SAME constant for every haplotype k
 // that both rows carry, not 1: the A side turns hap bit i of a nibble into the byte 1 << i (a byte replicate
@@ -183,10 +186,11 @@ constexpr uint32_t kSchedSlots = 256;
 // per CU into its K loop at a time; the other is in its epilogue (VALU) or waits.  While the epilogue is not shorter
 // than the K loop nobody waits and each K loop has the matrix pipe to itself.
 constexpr uint32_t kCuSlots = 2048;
-constexpr uint32_t kSchedWords = 2u + kCuSlots;
+constexpr uint32_t kSchedDone = 2u + kCuSlots;   // ... and the sequence number of the last launch that has FINISHED on the slot
+constexpr uint32_t kSchedWords = 3u + kCuSlots;
 __device__ uint32_t g_sched[kSchedSlots][kSchedWords];
 __device__ unsigned long long g_dbg[8];   // tuning builds (-DLDX_TUNING): event counters, see ldx_debug_counters
-#ifdef LDX_TUNING
+#if defined(LDX_TUNING) && !defined(LDX_STAMPS_ONLY)
 #define LDX_COUNT(slot, v) do { if (lane == 0) atomicAdd(&g_dbg[slot], (unsigned long long)(v)); } while (0)
 #else
 #define LDX_COUNT(slot, v)
@@ -208,7 +212,8 @@ struct AreaArgs {
     uint64_t hit_cap;
     double flank, k_thres;
     int measure;
-    F32Const f32;                  // the fp32 epilogue tier's constants (triangle launches use only this member)
+    F32Const f32;                  // the fp32 epilogue tier's constants (triangle launches use only this member and the next)
+    uint32_t launch_seq;           // this launch's number on its ticket-counter slot (acquire_sched): written back when it ends
 };
 constexpr uint32_t kHitBatch = 256;   // hit slots a wave reserves per atomic (as in ldx_area.hip)
 #ifdef LDX_MM1   // tuning build with three workgroups per CU: 53 KB of LDS each
@@ -221,7 +226,7 @@ constexpr uint32_t kQueueCap = 128;   // fp32 tier: lane-steps a wave can park f
 constexpr size_t mfma_lds_bytes(uint32_t stat_rows, bool f32_tier)
 {
     return 2u * kBBuf + (kSlab + kMfmaWaves * stat_rows) * kStat * sizeof(double) + 32u +
-           (f32_tier ? (kSlab + kMfmaWaves * kRows64) * 16u + kMfmaWaves * kQueueCap * 36u : 0u);
+           (f32_tier ? (kSlab + kMfmaWaves * kRows64) * 16u + kMfmaWaves * kQueueCap * 36u + kMfmaWaves * 64u * 4u : 0u);
 }
 
 // tuning build -DLDX_MM1: every ticket half-height (32-row accumulator tiles only), three workgroups per CU
@@ -256,6 +261,26 @@ __device__ __forceinline__ void store_cell_saddr(Cell *sbase, uint32_t voff_byte
         asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3 nt" : : "v"(voff_bytes), "v"(__builtin_bit_cast(unsigned long long, v)), "s"(sbase), "n"(kOffset) : "memory");
 }
 
+// A lane's four cells of one row -- adjacent in memory (LDX_CELL_OFFSET4 / 8) -- as ONE 16-byte store (two for 8-byte cells),
+// scalar row base + per-lane byte offset, non-temporal.  The CU's vector-memory unit takes a wave's store instruction at
+// the same cost whatever its width, and eight 4-byte stores per step and wave held the fp32 tier's step at ~1450 cycles
+// whatever its arithmetic cost (tools/probes/epi.hip: 990 alone; no stores at all: -19 % kernel time at 50 000 x 1008).
+template <typename Cell>
+__device__ __forceinline__ void store_cells4_saddr(Cell *sbase, uint32_t voff_bytes, Cell c0, Cell c1, Cell c2, Cell c3)
+{
+    if constexpr (sizeof(Cell) == 4) {
+        const v4u v = {__builtin_bit_cast(uint32_t, c0), __builtin_bit_cast(uint32_t, c1), __builtin_bit_cast(uint32_t, c2),
+                       __builtin_bit_cast(uint32_t, c3)};
+        asm volatile("global_store_dwordx4 %0, %1, %2 nt" : : "v"(voff_bytes), "v"(v), "s"(sbase) : "memory");
+    } else {
+        const v2u a = __builtin_bit_cast(v2u, c0), b = __builtin_bit_cast(v2u, c1), c = __builtin_bit_cast(v2u, c2),
+                  d = __builtin_bit_cast(v2u, c3);
+        const v4u lo = {a.x, a.y, b.x, b.y}, hi = {c.x, c.y, d.x, d.y};
+        asm volatile("global_store_dwordx4 %0, %1, %2 nt" : : "v"(voff_bytes), "v"(lo), "s"(sbase) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, %2 offset:512 nt" : : "v"(voff_bytes), "v"(hi), "s"(sbase) : "memory");   // 64 cells on
+    }
+}
+
 // kFp4: the counting runs on v_mfma_f32_32x32x64_f8f6f4 with FP4 operands (expand32_a4 / expand32_b4) instead of
 // v_mfma_i32_32x32x32_i8: a K-block is then 256 haplotypes -- two 128-haplotype chunks, one per lane half -- in four
 // steps of 64, so the loop below keeps its shape (per step 8 MFMAs, 4 fragment reads, one quarter of the thread's share
@@ -278,7 +303,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
     // counting), 4 = no stores, 16 = no epilogue priority, 64 = first half of the grid K loop only / second half
     // epilogue only, 128 = only the first half of the grid works, 512 = no clean-unit epilogue.  Results are wrong
     // by design for bits 1, 2, 4, 64, 128.
-#ifdef LDX_TUNING
+#if defined(LDX_TUNING) && !defined(LDX_STAMPS_ONLY)
     int ablate = ablate_arg;
     if (ablate_arg & 64) ablate = (blockIdx.x < (gridDim.x + 1) / 2) ? 5 : 2;
     if ((ablate_arg & 128) && blockIdx.x >= (gridDim.x + 1) / 2) return;
@@ -340,6 +365,8 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
     uint32_t *qid = reinterpret_cast<uint32_t *>(ctab32 + kSlab * 4u + kMfmaWaves * kRows64 * 4u) + wave * kQueueCap;   // [kQueueCap]
     float *qcnt = reinterpret_cast<float *>(reinterpret_cast<uint32_t *>(ctab32 + kSlab * 4u + kMfmaWaves * kRows64 * 4u) +
                                             kMfmaWaves * kQueueCap) + wave * (kQueueCap * 8u);   // [kQueueCap][8] counts
+    uint32_t *ulist = reinterpret_cast<uint32_t *>(ctab32 + kSlab * 4u + kMfmaWaves * kRows64 * 4u) + kMfmaWaves * kQueueCap * 9u +
+                      wave * 64u;   // [64]: parked pairs deferred to the mirror batch (entry << 3 | pair)
     const F32Const fc32 = aa.f32;   // computed on the host (f32_const): kernel arguments live in scalar registers
     auto draw = [&]() { return atomicAdd(&sched[0], 1u); };
     // this CU's K-loop token: OFF in product builds.  Tuning builds switch it on with LDX_ABLATE bit 4096 to make the
@@ -362,6 +389,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
         if (ticket >= n_tickets) {   // block-uniform; the last workgroup out re-arms the counters
             if (tid == 0 && atomicAdd(&sched[1], 1u) == gridDim.x - 1u) {
                 sched[1] = 0u;
+                sched[kSchedDone] = aa.launch_seq;   // the host may hand an idle slot to another stream (acquire_sched)
                 __threadfence();
                 sched[0] = 0u;
             }
@@ -546,13 +574,14 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                     dst[1] = d2{c.rr, c.rq};
                     if (kArea) dst[2] = j < n_snps ? d2{(double)aa.pos[j], (double)aa.is_query[j]} : d2{0.0, 0.0};
                     if constexpr (kF32Tier) {
-                        const F32Col c32 = f32_col(c.a, c.ra, c.rr);
+                        const F32Col c32 = f32_col(c.a, c.ra, c.rr, !odd);
                         *reinterpret_cast<v4f *>(ctab32 + tid * 4u) = v4f{c32.a, c32.ra, c32.rr, c32.s};
                     }
                 }
                 const uint32_t i = row0 + (MM == 1 ? l32 : lane);   // a half-height unit has 32 rows: stay inside the padded vectors
                 const FastRow r = fast_row(fa[i], fr[i], n);
-                rows_ordinary = __all(fast_ordinary(fa[i], fr[i], n));
+                const bool row_ordinary = fast_ordinary(fa[i], fr[i], n);
+                rows_ordinary = __all(row_ordinary);
                 typedef double d2 __attribute__((ext_vector_type(2)));
                 d2 *dst = reinterpret_cast<d2 *>(rstat + (lane < (kArea ? kRows64 : kStatRows) ? lane : 0u) * kStat);
                 if (lane < (kArea ? kRows64 : kStatRows)) {
@@ -560,7 +589,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                     dst[1] = d2{r.rr, r.rq_s};
                 }
                 if constexpr (kF32Tier) {   // (a half-height unit's lanes 32-63 repeat rows 0-31 into slots nobody reads)
-                    const F32Row r32 = f32_row(r.a_s * 1e-4, r.ra, r.rr);   // 1e4 a / 1e4: exact (a < 2^32)
+                    const F32Row r32 = f32_row(r.a_s * 1e-4, r.ra, r.rr, row_ordinary);   // 1e4 a / 1e4: exact (a < 2^32)
                     *reinterpret_cast<v4f *>(rtab32 + lane * 4u) = v4f{r32.a, r32.ra_s, r32.rr_s, r32.s};
                 }
                 if (kArea) dst[2] = i < n_snps ? d2{(double)aa.pos[i], (double)aa.is_query[i]} : d2{0.0, 0.0};
@@ -809,7 +838,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
 #pragma unroll
                         for (int tt = 0; tt < 4; ++tt) {
                             const uint32_t jl = 32u * tt + l32;
-                            const size_t o = (size_t)(us[m] - u_begin) * LDX_UNIT_PAIRS + (size_t)((ri[m] + roff) % kGroup) * kSlab + jl;
+                            const size_t o = (size_t)(us[m] - u_begin) * LDX_UNIT_PAIRS + cell_offset<Cell>((ri[m] + roff) % kGroup, jl);
                             Cell w = res[m][tt];
                             if (!kClean && !valid[m][tt]) w = zero_cell<Cell>();
                             store_cell(out + o, w);
@@ -826,7 +855,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
             // fp64 tier (ld_multi_fast2, and the op-for-op mirror behind it) has the registers it wants -- eight entries
             // at a time, one parked PAIR per lane: the rare path runs at full lane occupancy.  A unit that parks more steps
             // than the queue holds is redone as a whole by the fp64 epilogue (returns false).
-            auto epilogue_f32 = [&]() -> bool {
+            auto epilogue_f32 = [&](bool all_ordinary) -> bool {
               if constexpr (kF32Tier) {
                 if (ablate & 1) return true;   // tuning: no epilogue at all
                 // this unit's cells: a wave-uniform base (scalar registers) + a per-lane constant + a per-step scalar offset
@@ -839,7 +868,10 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 uint32_t ln = lane;
                 asm volatile("" : "+v"(ln));
                 const uint32_t l32e = ln & 31u, halfe = ln >> 5;
-                const uint32_t lane_off = halfe * 4u * kSlab + l32e;   // rows e and e + 4 of a group of 8 belong to the two lane halves
+                // rows e and e + 4 of a group of 8 belong to the two lane halves; a lane's four columns (l32 + 32 tt) are adjacent
+                // cells of the row (include/ldx.h: 4 l32 .. 4 l32 + 3 for 4-byte cells; the pairs 2 l32, 2 l32 + 1 and 64 + 2 l32,
+                // 65 + 2 l32 for 8-byte cells): one 16-byte store per row, or two
+                const uint32_t lane_off = halfe * 4u * kSlab + (sizeof(Cell) == 4 ? 4u : 2u) * l32e;
                 const uint32_t lane_off_b = lane_off * (uint32_t)sizeof(Cell);
                 const float *const rt = rtab32 + halfe * 16u, *const ct = ctab32 + l32e * 4u;
                 const uint32_t grp0 = roff / kGroup;   // first 8-row group of this wave's rows inside the unit (scalar)
@@ -854,6 +886,9 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 auto steps = [&](auto small_c) -> bool {
 #pragma unroll 1
                 for (int e = 0; e < 16; ++e) {
+#if defined(LDX_TUNING) && defined(LDX_STAMPS_ONLY)
+                    if (my_stamps && lane == 0 && npass == 1) my_stamps[6 + 4 * kStampPasses + e] = __builtin_amdgcn_s_memtime();
+#endif
                     F32Row rows[MM];
 #pragma unroll
                     for (int m = 0; m < MM; ++m) {   // two addresses per wave: broadcast
@@ -877,17 +912,21 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                         for (int tt = 0; tt < 4; ++tt) cell[g * 4 + tt] = o4[tt];
                     }
                     const bool sure = ((wmax < fc32.tol) & (ymin > 0.0f)) | ((ablate & 1024) != 0);   // tuning: 1024 = never park
+#ifdef LDX_AB_NOSTORE   // tuning: the cells are computed and kept alive, not stored (results missing)
+                    if (sure) {
+                        uint32_t x = 0;
+#pragma unroll
+                        for (int q8 = 0; q8 < 4 * MM; ++q8) { if constexpr (sizeof(Cell) == 4) x ^= __builtin_bit_cast(uint32_t, cell[q8]); else x ^= (uint32_t)__builtin_bit_cast(unsigned long long, cell[q8]) ^ (uint32_t)(__builtin_bit_cast(unsigned long long, cell[q8]) >> 32); }
+                        asm volatile("" : : "v"(x));
+                    }
+                    if (false) {
+#else
                     if (sure && !(ablate & 4)) {
+#endif
 #pragma unroll
                         for (int m = 0; m < MM; ++m) {   // groups of 8 rows: 4 m + e / 4 of a whole unit, 4 hsel + e / 4 of a half-height one
                             Cell *const row = ubase + ((4u * m + grp0 + (e >> 2)) * LDX_UNIT_PAIRS + (e & 3) * kSlab);   // scalar
-#pragma unroll
-                            for (int tt = 0; tt < 4; ++tt) {   // scalar row base + this lane's byte offset + the column tile's constant
-                                if (tt == 0) store_cell_saddr<0>(row, lane_off_b, cell[m * 4 + 0]);
-                                if (tt == 1) store_cell_saddr<32 * (int)sizeof(Cell)>(row, lane_off_b, cell[m * 4 + 1]);
-                                if (tt == 2) store_cell_saddr<64 * (int)sizeof(Cell)>(row, lane_off_b, cell[m * 4 + 2]);
-                                if (tt == 3) store_cell_saddr<96 * (int)sizeof(Cell)>(row, lane_off_b, cell[m * 4 + 3]);
-                            }
+                            store_cells4_saddr(row, lane_off_b, cell[m * 4 + 0], cell[m * 4 + 1], cell[m * 4 + 2], cell[m * 4 + 3]);
                         }
                     }
                     const unsigned long long parked = __ballot(!sure);
@@ -908,6 +947,9 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                         qn += np;
                     }
                 }
+#if defined(LDX_TUNING) && defined(LDX_STAMPS_ONLY)
+                    if (my_stamps && lane == 0 && npass == 1) my_stamps[6 + 4 * kStampPasses + 16] = __builtin_amdgcn_s_memtime();
+#endif
                     return true;
                 };
                 if (!(f32_small_n((double)fc32.n) ? steps(std::true_type{}) : steps(std::false_type{}))) return false;
@@ -926,30 +968,70 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 uint32_t ld = ln;
                 asm volatile("" : "+v"(ld));
                 constexpr uint32_t kPer = 4u * MM, kShift = MM == 2 ? 3u : 2u;   // lanes per parked step
+                // Two phases.  First the fp64 count-domain tier on every parked pair; a pair it cannot call either (near a
+                // rounding tie, Dn == 0) is DEFERRED to a list in LDS instead of being sent through the op-for-op mirror on the
+                // spot: the mirror (three IEEE divisions, ~150 double-rate instructions, out of line) runs for the whole wave
+                // whenever one lane needs it, and with its handful of candidates per unit spread over the batches nearly
+                // every batch paid for it (50 000 x 1008: ~8 candidates and 2-3 batches per unit).  Then ONE mirror batch
+                // over the compacted list.  (More than 64 deferred pairs: the surplus takes the mirror at once, as before.)
+                auto pair_of = [&](uint32_t ent, uint32_t pr, uint32_t &ri2, uint32_t &cl) {
+                    const uint32_t id = qid[ent];
+                    const uint32_t e2 = id >> 8, l2 = id & 31u, h2 = (id >> 5) & 1u;
+                    ri2 = 32u * (pr >> 2) + (e2 & 3u) + 8u * (e2 >> 2) + 4u * h2;
+                    cl = 32u * (pr & 3u) + l2;
+                    return qcnt[(size_t)ent * 8u + pr];
+                };
+                auto mirror_cell = [&](float cnt, uint32_t ri2, uint32_t cl) {
+                    const uint32_t i = row0 + ri2, j = t * kSlab + cl;
+#if defined(LDX_TUNING) && !defined(LDX_STAMPS_ONLY)
+                    atomicAdd(&g_dbg[3], 1ull);
+#endif
+                    return encode_cell<Cell>(ld_pair_mirror((double)cnt / n, fa[i], fr[i], q[i], fa[j], fr[j]));
+                };
+                auto cell_at = [&](uint32_t ri2, uint32_t cl) -> Cell & {
+                    return ubase[(size_t)(grp0 + ri2 / kGroup) * LDX_UNIT_PAIRS + cell_offset<Cell>(ri2 % kGroup, cl)];
+                };
+                uint32_t un = 0;   // deferred pairs (wave-uniform)
                 for (uint32_t q0 = 0; q0 < qn; q0 += 64u / kPer) {   // wave-uniform
                     const uint32_t ent = q0 + (ld >> kShift), pr = ld & (kPer - 1u);
-                    if (ent < qn) {
-                        const uint32_t id = qid[ent];
-                        const uint32_t e2 = id >> 8, l2 = id & 31u, h2 = (id >> 5) & 1u;
-                        const float a2[1] = {qcnt[(size_t)ent * 8u + pr]};
-                        const uint32_t ri2 = 32u * (pr >> 2) + (e2 & 3u) + 8u * (e2 >> 2) + 4u * h2, cl = 32u * (pr & 3u) + l2;
+                    const bool live = ent < qn;
+                    uint32_t ri2 = 0, cl = 0;
+                    Cell r2[1] = {zero_cell<Cell>()};
+                    bool s2[1] = {false};
+                    float a2[1] = {0.0f};
+                    if (live) {
+                        a2[0] = pair_of(ent, pr, ri2, cl);
                         const d2 *rs = reinterpret_cast<const d2 *>(rstat + ri2 * kStat);
                         const d2 r01 = rs[0], r23 = rs[1];
                         const FastRow frk[1] = {FastRow{r01.x, r01.y, r23.x, r23.y}};
                         const d2 *cs = reinterpret_cast<const d2 *>(cstat + cl * kStat);
                         const d2 c01 = cs[0], c23 = cs[1];
                         const FastCol fcx[1] = {FastCol{c01.x, c01.y, c23.x, c23.y}};
-                        Cell r2[1];
-                        bool s2[1];
-                        ld_multi_fast2<1, true, Cell>(a2, fk, frk, fcx, r2, s2);
-                        if (s2[0]) {   // near a rounding tie, Dn == 0: the exact mirror
-                            const uint32_t i = row0 + ri2, j = t * kSlab + cl;
-                            r2[0] = encode_cell<Cell>(ld_pair_mirror((double)a2[0] / n, fa[i], fr[i], q[i], fa[j], fr[j]));
-#ifdef LDX_TUNING
-                            atomicAdd(&g_dbg[3], 1ull);
-#endif
+                        if (all_ordinary) ld_multi_fast2<1, true, Cell>(a2, fk, frk, fcx, r2, s2);
+                        else ld_multi_fast2<1, false, Cell>(a2, fk, frk, fcx, r2, s2);   // a monomorphic SNP / missing codes in the unit
+                    }
+                    const bool unsure = live && s2[0];
+                    const unsigned long long um = __ballot(unsure);
+                    bool deferred = false;
+                    if (um) {   // wave-uniform
+                        const uint32_t pos = un + __builtin_amdgcn_mbcnt_hi((uint32_t)(um >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)um, 0u));
+                        deferred = unsure && pos < 64u;
+                        if (deferred) ulist[pos] = (ent << 3) | pr;
+                        un += (uint32_t)__builtin_popcountll(um);
+                        if (__builtin_expect(un > 64u, 0)) {   // the list is full: these take the mirror now
+                            if (unsure && !deferred) r2[0] = mirror_cell(a2[0], ri2, cl);
                         }
-                        ubase[(size_t)(grp0 + ri2 / kGroup) * LDX_UNIT_PAIRS + (ri2 % kGroup) * kSlab + cl] = r2[0];
+                    }
+                    if (live && !deferred) cell_at(ri2, cl) = r2[0];
+                }
+                if (un) {   // phase 2: the deferred pairs, one mirror batch
+                    __builtin_amdgcn_s_waitcnt(0xC07F);
+                    __builtin_amdgcn_wave_barrier();
+                    if (ld < (un < 64u ? un : 64u)) {
+                        const uint32_t id = ulist[ld];
+                        uint32_t ri2, cl;
+                        const float cnt = pair_of(id >> 3, id & 7u, ri2, cl);
+                        cell_at(ri2, cl) = mirror_cell(cnt, ri2, cl);
                     }
                 }
                 return true;
@@ -1079,12 +1161,19 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 if (!(ablate & 16)) __builtin_amdgcn_s_setprio(0);
                 return;
             }
-            const bool clean = !kRaw && rows_ordinary && (cols_odd[0] | cols_odd[1]) == 0u &&
-                               row0 >= (t + 1u) * kSlab && row0 + 32u * MM <= n_snps && (t + 1u) * kSlab <= n_snps &&
-                               vv * 8u >= u_begin && vv * 8u + 8u <= u_end;
+            // `inside`: the unit lies wholly below the diagonal, inside the panel and inside [u_begin, u_end) (no validity
+            // tests); `clean`: and all of its 64 rows and 128 columns are ordinary SNPs (no degenerate handling either)
+            const bool inside = !kRaw && row0 >= (t + 1u) * kSlab && row0 + 32u * MM <= n_snps && (t + 1u) * kSlab <= n_snps &&
+                                vv * 8u >= u_begin && vv * 8u + 8u <= u_end;
+            const bool all_ordinary = rows_ordinary && (cols_odd[0] | cols_odd[1]) == 0u;
+            const bool clean = inside && all_ordinary;
             if constexpr (kF32Tier) {
-                if (clean && !(ablate & 512)) {
-                    if (!epilogue_f32()) epilogue(std::true_type{});   // queue overflow: the whole unit again, fp64
+                // The fp32 tier takes every `inside` unit: rows / columns of SNPs that are not ordinary park their lane-steps
+                // (ldx_common.h, f32_row) and the drain runs the general fp64 variant for such a unit.  A unit that parks more
+                // than the queue holds (four or more such SNPs) goes through the fp64 epilogue whole.
+                if (inside && !(ablate & 512) && epilogue_f32(all_ordinary)) {
+                } else if (clean && !(ablate & 512)) {
+                    epilogue(std::true_type{});
                 } else {
                     epilogue(std::false_type{});
                 }
@@ -1120,13 +1209,19 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
             if (sl < aa.hit_cap) aa.hits[sl].query = 0xFFFFFFFFu;
 }
 
-// One ticket-counter pair per (device, stream): launches of one stream are ordered, so they may share it; launches of
-// different streams (or devices) may overlap, so they must not.  The pairs live in the per-device instance of g_sched;
-// a slot is zeroed ONCE, on the stream that acquires it, and from then on every launch leaves it re-armed (the last
-// workgroup out resets both words), so a launch costs no memset node.  A slot is NEVER taken away from its stream: a
-// captured HIP graph has the slot's address baked into its kernel nodes, and a live stream may have a launch in flight on
-// it -- the 257th distinct stream of a device gets LDX_E_UNSUPPORTED instead of somebody else's counters.
-static int acquire_sched(hipStream_t s, uint32_t **sched)
+// One ticket-counter slot per (device, stream): launches of one stream are ordered, so they may share it; launches of
+// different streams (or devices) may overlap, so they must not.  The slots live in the per-device instance of g_sched;
+// a slot is zeroed on the stream that acquires it, and from then on every launch leaves it re-armed (the last
+// workgroup out resets both words), so a launch costs no memset node.
+// Reclaiming (round 4).  A process that keeps creating streams (one per chromosome, per table ...) runs out of the 256
+// slots of a device.  Every launch carries a sequence number (AreaArgs::launch_seq) that its last workgroup writes back
+// into the slot; when no slot is free the host reads the 256 numbers (one small copy on a private stream) and takes a slot
+// whose last ISSUED launch has FINISHED -- whatever became of the stream that owned it (destroyed, idle, reused) -- and
+// that was never used under stream capture (a captured graph has the slot's address baked into its kernel nodes and may be
+// replayed at any time).  The old owner, should it launch again, simply acquires a slot anew.  Only when all 256 slots are
+// in flight or captured does the call fail: kNoSlot, which the entry points turn into the popcount kernel for
+// LDX_PATH_AUTO (identical results) and into LDX_E_UNSUPPORTED for an explicit matrix-pipe path.
+static int acquire_sched(hipStream_t s, uint32_t **sched, uint32_t *launch_seq)
 {
     struct Key {
         int dev;
@@ -1136,21 +1231,35 @@ static int acquire_sched(hipStream_t s, uint32_t **sched)
     struct KeyHash {
         size_t operator()(const Key &k) const { return std::hash<void *>()((void *)k.s) * 31u + (size_t)k.dev; }
     };
+    struct Slot {
+        hipStream_t owner = nullptr;
+        uint32_t issued = 0;       // sequence number of the last launch issued on the slot
+        bool in_use = false;
+        bool captured = false;     // a launch was recorded into a graph: never reclaimed
+    };
     struct PerDevice {
         uint32_t (*pool)[kSchedWords] = nullptr;   // this device's g_sched
-        uint32_t next_slot = 0;                    // slots handed out so far (never reclaimed)
+        Slot slots[kSchedSlots];
+        uint32_t next_slot = 0;                    // slots handed out for the first time so far
+        hipStream_t aux = nullptr;                 // private non-blocking stream of the reclaiming copy
     };
     static std::mutex sched_mutex;
     static std::unordered_map<Key, uint32_t, KeyHash> sched_slot;
-    static PerDevice per_dev[64];
+    static PerDevice *per_dev[64] = {};
     int dev = 0;
     LDX_HIP(hipGetDevice(&dev));
     LDX_REQUIRE(dev >= 0 && dev < 64, "device ordinal out of range");
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) {
+        (void)hipGetLastError();
+        cap = hipStreamCaptureStatusNone;
+    }
     bool fresh = false;
-    uint32_t slot;
+    uint32_t slot = 0;
     {
         std::lock_guard<std::mutex> lock(sched_mutex);
-        PerDevice &pd = per_dev[dev];
+        if (!per_dev[dev]) per_dev[dev] = new PerDevice();
+        PerDevice &pd = *per_dev[dev];
         if (!pd.pool) {
             void *sym = nullptr;
             LDX_HIP(hipGetSymbolAddress(&sym, HIP_SYMBOL(g_sched)));   // the current device's copy of the symbol
@@ -1158,21 +1267,50 @@ static int acquire_sched(hipStream_t s, uint32_t **sched)
         }
         const Key key{dev, s};
         auto it = sched_slot.find(key);
-        if (it == sched_slot.end()) {   // a new stream takes the next free slot, for the life of the process
-            if (pd.next_slot >= kSchedSlots) {
-                set_error("ld_triangle on the matrix pipe: more than %u distinct streams on device %d (one ticket-counter "
-                          "slot per stream, never reclaimed); reuse streams, or use LDX_PATH_POPCOUNT on the others",
-                          kSchedSlots, dev);
-                return LDX_E_UNSUPPORTED;
+        if (it != sched_slot.end()) {
+            slot = it->second;
+        } else {
+            if (pd.next_slot < kSchedSlots) {
+                slot = pd.next_slot++;
+            } else {   // all handed out: look for one whose last launch has finished
+                if (cap != hipStreamCaptureStatusNone) {   // (no copies or synchronisation while the caller captures)
+                    set_error("ld_triangle on the matrix pipe: no free ticket-counter slot on device %d and the stream is "
+                              "capturing; capture on a stream that has launched before", dev);
+                    return kNoSlot;
+                }
+                if (!pd.aux) LDX_HIP(hipStreamCreateWithFlags(&pd.aux, hipStreamNonBlocking));
+                static thread_local uint32_t done[kSchedSlots];
+                LDX_HIP(hipMemcpy2DAsync(done, sizeof(uint32_t), &pd.pool[0][kSchedDone], kSchedWords * sizeof(uint32_t),
+                                         sizeof(uint32_t), kSchedSlots, hipMemcpyDeviceToHost, pd.aux));
+                LDX_HIP(hipStreamSynchronize(pd.aux));
+                bool found = false;
+                for (uint32_t k = 0; k < kSchedSlots && !found; ++k) {
+                    const Slot &c = pd.slots[k];
+                    if (c.in_use && !c.captured && done[k] == c.issued) {
+                        sched_slot.erase(Key{dev, c.owner});
+                        slot = k;
+                        found = true;
+                    }
+                }
+                if (!found) {
+                    set_error("ld_triangle on the matrix pipe: all %u ticket-counter slots of device %d are in flight or "
+                              "belong to captured graphs", kSchedSlots, dev);
+                    return kNoSlot;
+                }
             }
-            slot = pd.next_slot++;
+            pd.slots[slot] = Slot{};
+            pd.slots[slot].owner = s;
+            pd.slots[slot].in_use = true;
             sched_slot.emplace(key, slot);
             fresh = true;
-        } else {
-            slot = it->second;
         }
+        Slot &mine = pd.slots[slot];
+        if (cap != hipStreamCaptureStatusNone) mine.captured = true;
+        *launch_seq = ++mine.issued;
         *sched = pd.pool[slot];
     }
+    // (a reclaimed slot is all zeros already -- its last launch re-armed it -- except for the done word; zeroing it on the
+    // new owner's stream keeps the two cases one)
     if (fresh) LDX_HIP(hipMemsetAsync(*sched, 0, kSchedWords * sizeof(uint32_t), s));
     return LDX_OK;
 }
@@ -1227,8 +1365,8 @@ static int launch_mfma(const void *alt, const double *fa, const double *fr, cons
     if (grid > (uint64_t)n_pass + n_short) grid = (uint64_t)n_pass + n_short;
     if (grid < 1) grid = 1;
     uint32_t *sched = nullptr;
-    if (int rc = acquire_sched(s, &sched)) return rc;
     AreaArgs tri_args{};
+    if (int rc = acquire_sched(s, &sched, &tri_args.launch_seq)) return rc;
     tri_args.f32 = f32_const((double)n_hap);
     int ablate = 0;
     unsigned long long *stamps = nullptr;
@@ -1372,8 +1510,8 @@ int area_mfma(const void *alt, const double *fa, const double *fr, const double 
     const size_t lds = mfma_lds_bytes(kRows64, false);
     const int cus = device_cus();
     uint32_t *sched = nullptr;
-    if (int rc = acquire_sched(s, &sched)) return rc;
     AreaArgs aa{};
+    if (int rc = acquire_sched(s, &sched, &aa.launch_seq)) return rc;
     aa.pos = positions;
     aa.is_query = is_query;
     aa.pass_base = pass_base;

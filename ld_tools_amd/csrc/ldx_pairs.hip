@@ -80,7 +80,7 @@ triangle_kernel(const uint4 *__restrict__ alt, const double *__restrict__ fa, co
                 for (int jj = 0; jj < 2; ++jj) {
                     const uint32_t j = jj ? j1 : j0;
                     const bool valid = (i > j) && (i < n_snps);   // ld_triangle.py:149-150
-                    const size_t o = obase + LDX_CELL_OFFSET((uint32_t)r, jj * 64u + lane);
+                    const size_t o = obase + cell_offset<Cell>((uint32_t)r, jj * 64u + lane);
                     Cell res = zero_cell<Cell>();
                     ldx_ld64 rw = {0.0, 0.0};
                     if (valid) {
@@ -201,8 +201,8 @@ __device__ inline Cell all_tiers(double n, double rn, uint32_t c11, double fa1, 
             same = same && same_cell(g_[0], res);
             // the fp32 first tier of the FP4 kernel: whenever it calls a pair sure, its cell must be the mirror's
             const F32Const f32k = f32_const(n);
-            const F32Row r32[1] = {f32_row(fr_[0].a_s * 1e-4, fr_[0].ra, fr_[0].rr)};
-            const F32Col c32[1] = {f32_col(fc_[0].a, fc_[0].ra, fc_[0].rr)};
+            const F32Row r32[1] = {f32_row(fr_[0].a_s * 1e-4, fr_[0].ra, fr_[0].rr, true)};
+            const F32Col c32[1] = {f32_col(fc_[0].a, fc_[0].ra, fc_[0].rr, true)};
             Cell h_[1];
             float wmax = 0.0f, ymin = 1.0f;
             if (f32_small_n(n)) ld_multi_f32<1, Cell, true>(cnt_, f32k, r32, c32, h_, wmax, ymin);   // the variant the kernel picks for this n
@@ -326,7 +326,7 @@ __global__ void triangle_dense_kernel(const Cell *__restrict__ strips, uint32_t 
         const uint64_t G = (uint64_t)n_slabs * kGroupsPerSlab;
         const uint32_t t = j / kSlab, g = i / kGroup;
         const uint64_t u = tile_base(t, G) + (g - t * kGroupsPerSlab);
-        const Cell c = strips[u * LDX_UNIT_PAIRS + LDX_CELL_OFFSET(i % kGroup, j % kSlab)];
+        const Cell c = strips[u * LDX_UNIT_PAIRS + cell_offset<Cell>(i % kGroup, j % kSlab)];
         double k;
         v = dense_value(c, measure, &k);
         // ld_triangle.py:223-225 compares the rounded value k/10^4 with the threshold; k_thres is the
@@ -449,9 +449,13 @@ extern "C" int ldx_triangle_ex_dev(const void *alt, const double *fa, const doub
     if (unit_end > U) unit_end = U;
     if (unit_begin >= unit_end) return LDX_OK;
     hipStream_t s = (hipStream_t)stream;
-    if (path != LDX_PATH_POPCOUNT)   // AUTO = the FP4 matrix kernel (twice the int8 kernel's counting rate)
-        return triangle_mfma(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end, out_format, out, out_raw, out_n11,
-                             path != LDX_PATH_MFMA, s);
+    if (path != LDX_PATH_POPCOUNT) {   // AUTO = the FP4 matrix kernel (twice the int8 kernel's counting rate)
+        const int rc = triangle_mfma(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end, out_format, out, out_raw, out_n11,
+                                     path != LDX_PATH_MFMA, s);
+        if (rc != ldx::kNoSlot) return rc;
+        if (path != LDX_PATH_AUTO) return LDX_E_UNSUPPORTED;   // an explicit matrix-pipe path: say so (message set)
+        // AUTO and no ticket-counter slot for this stream: the popcount kernel gives the very same cells
+    }
     if (out_format == LDX_OUT_K16) {
         ldx_k16 *o = (ldx_k16 *)out;
         if (out_n11)

@@ -84,7 +84,7 @@ class TriangleResult:
         t = cols // 128
         g = rows // 8
         u = t * G - 8 * t * (t - 1) + (g - 16 * t)
-        return (u - self.unit_begin) * UNIT_PAIRS + _lib.cell_offset(rows % 8, cols % 128)
+        return (u - self.unit_begin) * UNIT_PAIRS + _lib.cell_offset(rows % 8, cols % 128, self.fmt)
 
     def k_and_int0(self, idx) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
         """(k int64 [m, 2], int0 bool [m, 2], escape bool [m, 2]) of the cells at flat indices ``idx`` (host arrays);

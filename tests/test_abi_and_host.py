@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(_lib.lib, n), f"{n} declared in ldx.h but not exported by libldx.so"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature in ld_tools_amd/_lib.py"
     assert set(_lib.SIGNATURES) == set(names)
-    assert _lib.version() == 100
+    assert _lib.version() == 101
 
 
 def test_no_torch_or_python_dependency_in_library():
@@ -125,13 +125,24 @@ def test_unit_cell_order_is_a_permutation_and_matches_the_library():
     from ld_tools_amd import _lib
 
     r, c = np.meshgrid(np.arange(8), np.arange(128), indexing="ij")
-    off = _lib.cell_offset(r, c)
-    assert sorted(off.ravel().tolist()) == list(range(1024))
     L = _lib.lib
-    for n in (130, 1000, 10000):
-        for row, col in ((1, 0), (n - 1, 0), (n - 1, n - 2), (129, 127), (n // 2, n // 3)):
-            u = L.ldx_triangle_unit_of(n, row, col)
-            assert L.ldx_triangle_cell_index(n, row, col) == u * 1024 + int(_lib.cell_offset(row % 8, col % 128))
+    for fmt in ("k16", "ld32"):
+        off = _lib.cell_offset(r, c, fmt)
+        assert sorted(off.ravel().tolist()) == list(range(1024))
+        # the four columns one lane of the matrix kernel holds (l, l + 32, l + 64, l + 96) are adjacent: all four (4-byte cells)
+        # or in two pairs (8-byte cells), so that the lane writes 16 bytes per store
+        for row in range(8):
+            for lane in range(32):
+                q = [int(_lib.cell_offset(row, lane + 32 * tt, fmt)) for tt in range(4)]
+                if fmt == "k16":
+                    assert q == [q[0] + k for k in range(4)] and q[0] % 4 == 0
+                else:
+                    assert q[1] == q[0] + 1 and q[3] == q[2] + 1 and q[0] % 2 == 0 and q[2] == q[0] + 64
+        for n in (130, 1000, 10000):
+            for row, col in ((1, 0), (n - 1, 0), (n - 1, n - 2), (129, 127), (n // 2, n // 3)):
+                u = L.ldx_triangle_unit_of(n, row, col)
+                assert L.ldx_triangle_cell_index(n, row, col, _lib.FORMATS[fmt]) == \
+                    u * 1024 + int(_lib.cell_offset(row % 8, col % 128, fmt))
 
 
 def test_device_calls_fail_loudly_without_gpu():

@@ -358,21 +358,23 @@ def test_triangle_k16_cells_equal_ld32_cells(gpu, path):
     a = ld_triangle(p, want_n11=True)
     b = ld_triangle(p, want_n11=True, fmt="k16")
     assert b.k16.dtype == torch.int16 and b.ld32 is None and b.fmt == "k16"
-    assert torch.equal(a.n11, b.n11)
     n = p.n_snps
     rows, cols = np.tril_indices(n, -1)
-    idx = a.cell_index(rows, cols)
+    idx, idx16 = a.cell_index(rows, cols), b.cell_index(rows, cols)   # each format has its own order inside a unit (include/ldx.h)
+    assert np.array_equal(a.n11.cpu().numpy()[idx], b.n11.cpu().numpy()[idx16])
     o = c_oracle.Panel(codes).triangle(libm_pow=True, want=("rsq_rnd", "dp_rnd", "flags"))
     k_true = np.stack([np.rint(o["rsq_rnd"][rows, cols] * 1e4), np.rint(o["dp_rnd"][rows, cols] * 1e4)], axis=1)
-    check_cells(k_true, o["flags"][rows, cols], a.ld32.cpu().numpy()[idx], b.k16.cpu().numpy()[idx], path)
+    check_cells(k_true, o["flags"][rows, cols], a.ld32.cpu().numpy()[idx], b.k16.cpu().numpy()[idx16], path)
     assert (k_true >= 1.024e7).any() and ((k_true >= 32767) & (k_true < 1.024e7)).any()
-    # cells outside the triangle are zero in both formats
-    mask = np.ones(len(b.k16), dtype=bool)
+    # cells outside the triangle are zero in both formats, and so are their counts
+    mask, mask16 = np.ones(len(b.k16), dtype=bool), np.ones(len(b.k16), dtype=bool)
     mask[idx] = False
-    assert not b.k16.cpu().numpy()[mask].any() and not a.ld32.cpu().numpy()[mask].any()
+    mask16[idx16] = False
+    assert not b.k16.cpu().numpy()[mask16].any() and not a.ld32.cpu().numpy()[mask].any()
+    assert not b.n11.cpu().numpy()[mask16].any() and not a.n11.cpu().numpy()[mask].any()
     # k_and_int0 decodes both the same way
     ka, za, ea = a.k_and_int0(idx)
-    kb, zb, eb = b.k_and_int0(idx)
+    kb, zb, eb = b.k_and_int0(idx16)
     both = ~ea & ~eb
     assert np.array_equal(ka[both], kb[both]) and np.array_equal(za, zb) and (ea <= eb).all()
     # the dense matrices agree wherever neither is an escape; k16's escapes are a superset
@@ -531,6 +533,12 @@ def test_triangle_bench_size_against_oracle_rows(gpu, path):
     assert torch.equal(plain.ld32.view(torch.int32), res.ld32.view(torch.int32))
     k16 = ld_triangle(p, fmt="k16").k16.cpu().numpy().view(np.uint16).astype(np.int64)
     want = np.where(np.signbit(ld32), 0x8000, k_of(ld32))
+    # the two formats order the cells of a unit differently (include/ldx.h): bring the ld32-order array into k16 order
+    from ld_tools_amd._lib import cell_offset
+    r8, c = np.meshgrid(np.arange(8), np.arange(128), indexing="ij")
+    src = np.empty(1024, dtype=np.int64)
+    src[cell_offset(r8, c, "k16").ravel()] = cell_offset(r8, c, "ld32").ravel()
+    want = want.reshape(-1, 1024, 2)[:, src, :].reshape(-1, 2)
     assert np.array_equal(k16, want)
 
 
@@ -561,6 +569,12 @@ def test_config4_triangle_50k_x_1008(gpu):
     del plain
     k16 = ld_triangle(p, fmt="k16", path="fp4")
     k_ref = torch.where(torch.signbit(ref.ld32), torch.full_like(ref.ld32, 32768.0), torch.round(ref.ld32.double() * 1e4).float())
+    # the two formats order the cells of a unit differently (include/ldx.h): bring the ld32-order tensor into k16 order
+    from ld_tools_amd._lib import cell_offset
+    r8, c = np.meshgrid(np.arange(8), np.arange(128), indexing="ij")
+    src = np.empty(1024, dtype=np.int64)
+    src[cell_offset(r8, c, "k16").ravel()] = cell_offset(r8, c, "ld32").ravel()
+    k_ref = k_ref.view(-1, 1024, 2)[:, torch.from_numpy(src).to(k_ref.device), :].reshape(-1, 2)
     assert torch.equal(k16.k16.to(torch.int32) & 0xFFFF, k_ref.to(torch.int32))
     for other in ("popcount", "mfma"):
         b = ld_triangle(p, fmt="k16", path=other)
@@ -723,6 +737,70 @@ def test_triangle_on_many_streams(gpu):
         assert torch.equal(o2.ld32.view(torch.int32), ref.view(torch.int32)), k
 
 
+def test_triangle_on_a_thousand_raw_streams(gpu):
+    """a driver that creates a raw hipStream_t per chromosome / table must not run out of ticket-counter
+    slots (256 per device).  1 000 streams made with hipStreamCreate (ctypes on libamdhip64: torch recycles a pool of 32,
+    so torch.cuda.Stream cannot reach the limit) are used once each with an EXPLICIT matrix-pipe path and destroyed: the
+    library takes back the slot of a stream whose last launch has finished.  Every result equals the single-stream one.
+    Then 300 streams are kept alive and busy at once -- more launches in flight than slots: with LDX_PATH_AUTO the surplus
+    falls back to the popcount kernel (same cells), with an explicit path it is refused loudly."""
+    import ctypes
+    import torch
+    from ld_tools_amd import PackedPanel, _lib, ld_triangle, synth
+    from ld_tools_amd._lib import lib
+
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipStreamCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+    hip.hipStreamDestroy.argtypes = [ctypes.c_void_p]
+    hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+    p = PackedPanel.from_codes(synth.synth_codes_device(300, 1008, seed=2))
+    ref = ld_triangle(p, fmt="k16", path="fp4")
+    torch.cuda.synchronize()
+    cells = ref.k16.numel() // 2
+    out = torch.empty_like(ref.k16)
+
+    def launch(stream, path, dst):
+        return lib.ldx_triangle_ex_dev(p.alt.data_ptr(), p.fa.data_ptr(), p.fr.data_ptr(), p.q.data_ptr(), p.n_snps, p.n_hap,
+                                       0, p.n_units, path, _lib.FORMATS["k16"], dst.data_ptr(), None, None, stream)
+
+    for k in range(1000):
+        st = ctypes.c_void_p()
+        assert hip.hipStreamCreate(ctypes.byref(st)) == 0
+        out.fill_(-1)
+        torch.cuda.synchronize()
+        rc = launch(st, 3, out)                      # LDX_PATH_FP4, explicit: no popcount fallback may hide a failure
+        assert rc == 0, (k, rc, lib.ldx_last_error())
+        assert hip.hipStreamSynchronize(st) == 0
+        assert torch.equal(out, ref.k16), k
+        assert hip.hipStreamDestroy(st) == 0
+    assert out.numel() == 2 * cells
+    # more streams in flight than slots: a long kernel on each of 300 live streams
+    big = PackedPanel.from_codes(synth.synth_codes_device(6000, 1008, seed=3))
+    bref = ld_triangle(big, fmt="k16", path="popcount")
+    torch.cuda.synchronize()
+    outs, streams, refused = [], [], 0
+    for k in range(300):
+        st = ctypes.c_void_p()
+        assert hip.hipStreamCreate(ctypes.byref(st)) == 0
+        streams.append(st)
+        o = torch.empty_like(bref.k16)
+        rc = lib.ldx_triangle_ex_dev(big.alt.data_ptr(), big.fa.data_ptr(), big.fr.data_ptr(), big.q.data_ptr(), big.n_snps,
+                                     big.n_hap, 0, big.n_units, 0, _lib.FORMATS["k16"], o.data_ptr(), None, None, st)   # AUTO
+        assert rc == 0, (k, rc, lib.ldx_last_error())
+        outs.append(o)
+        if k >= 280:                                 # by now every slot may be taken and busy: an explicit path must say so
+            rc = launch(st, 3, out)
+            assert rc in (0, -3), rc                 # LDX_OK or LDX_E_UNSUPPORTED -- never somebody else's counters
+            refused += rc == -3
+    for st in streams:
+        assert hip.hipStreamSynchronize(st) == 0
+    for k, o in enumerate(outs):
+        assert torch.equal(o, bref.k16), k
+    for st in streams:
+        assert hip.hipStreamDestroy(st) == 0
+    print(f"explicit-path launches refused while all slots were busy: {refused} of 20")
+
+
 def test_triangle_100k_shard_of_eight(gpu):
     """configs[3] (100 000 x 5008 over 8 GPUs): the unit range rank 3 of 8 would own, on one card.  The two kernels
     agree bit for bit on all 6.2e8 pairs of the shard, rows inside it match the C oracle, and the n11 mass of the
@@ -761,7 +839,7 @@ def test_triangle_100k_shard_of_eight(gpu):
         m = (u >= u0) & (u < u1)
         if not m.any():
             continue
-        idx = (u[m] - u0) * UNIT_PAIRS + cell_offset(row % 8, cols[m] % 128)
+        idx = (u[m] - u0) * UNIT_PAIRS + cell_offset(row % 8, cols[m] % 128, "ld32")
         c = cols[m]
         want_n = o.pair_counts(row, row + 1, int(c[0]), int(c[-1]) + 1)[0]        # the columns of a row's units are contiguous
         assert len(want_n) == len(c)
@@ -826,7 +904,7 @@ def test_config3_triangle_100k_all_eight_shards(gpu):
                 continue
             cm = cols[m]
             assert np.array_equal(cm, np.arange(cm[0], cm[-1] + 1))               # a row's units inside a range are contiguous
-            idx = torch.from_numpy((u[m] - u0) * UNIT_PAIRS + cell_offset(row % 8, cm % 128)).to(a.k16.device)
+            idx = torch.from_numpy((u[m] - u0) * UNIT_PAIRS + cell_offset(row % 8, cm % 128, "k16")).to(a.k16.device)
             want_n = o.pair_counts(row, row + 1, int(cm[0]), int(cm[-1]) + 1)[0]
             k = len(cm)
             _, _, w_rsq, w_dp, w_flags = c_oracle.ld_from_counts_v(

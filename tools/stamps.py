@@ -42,6 +42,16 @@ for idx in range(int(st[:, 3].max())):
     print(f"  pass #{idx}: n={len(sel):5d} start(p50, rel)={np.median(s4[:, 0] - tmin):9.0f}  K={np.median(s4[:, 2] - s4[:, 1]):7.0f}  E={np.median(s4[:, 3] - s4[:, 2]):7.0f}  end(p50)={np.median(s4[:, 3] - tmin):9.0f} end(max)={(s4[:, 3] - tmin).max():9.0f}")
     if idx >= 5: break
 
+# per-step stamps of the fp32 tier (builds with -DLDX_TUNING -DLDX_STAMPS_ONLY): the second pass of every wave
+if stride >= 6 + 4 * passes + 17:
+    ss = st[:, 6 + 4 * passes: 6 + 4 * passes + 17].astype(np.int64)
+    ss = ss[(ss[:, 0] > 0) & (ss[:, 16] > ss[:, 0])]
+    if len(ss):
+        d = np.diff(ss, axis=1)
+        print(f"fp32-tier steps of the second pass ({len(ss)} waves): cycles per step  " + q(d.ravel()) + f"  mean={d.mean():.0f}")
+        print("   by step index (median): " + " ".join(f"{np.median(d[:, k]):.0f}" for k in range(16)))
+        print("   sixteen steps together: " + q(ss[:, 16] - ss[:, 0]))
+
 # in-chunk stamps (builds with -DLDX_CHUNK_STAMPS): six s_memtime points of one chunk of each wave's second pass
 cs = st[:, 6 + 4 * (passes - 2): 6 + 4 * (passes - 2) + 6].astype(np.int64)
 cs = cs[(cs[:, 0] > 0) & (cs[:, 5] > cs[:, 0])]
