@@ -228,6 +228,14 @@ int ldx_area_dev(const void *alt, const double *fa, const double *fr, const doub
                  double thres, ldx_hit *hits, uint64_t hit_cap, uint64_t *n_hits, void *workspace,
                  size_t workspace_bytes, void *stream);
 size_t ldx_area_workspace_bytes(uint32_t n_snps, uint32_t n_hap, uint32_t n_query);
+/* The same scan, which also counts the stored hits per query row as it appends them: query_counts = device uint32
+ * [n_snps + 1] (zeroed here) or NULL.  With query_counts = ldx_area_finish_counts(finish workspace) the finishing step
+ * below (ldx_area_finish_ex_dev, counts_ready = 1) needs neither its memset nor its pass over the slot buffer. */
+int ldx_area_scan_dev(const void *alt, const double *fa, const double *fr, const double *q,
+                      uint32_t n_snps, uint32_t n_hap, const int64_t *positions,
+                      const uint32_t *queries, uint32_t n_query, int64_t flank, int measure,
+                      double thres, ldx_hit *hits, uint64_t hit_cap, uint64_t *n_hits, uint32_t *query_counts,
+                      void *workspace, size_t workspace_bytes, void *stream);
 /* Finish a scan on the device, without a host round trip: raw slots (arbitrary order, unused slots marked) -> hits
  * sorted by (query row, opposing row) = the reference's output order (ld_area.py:152,215-217), plus the per-row index
  * offsets[n_snps + 1] (hits of query row q are sorted[offsets[q] .. offsets[q + 1])).  n_reserved: the device counter
@@ -239,6 +247,10 @@ int ldx_area_finish_dev(ldx_hit *raw, const uint64_t *n_reserved, uint64_t hit_c
                         ldx_hit *sorted, uint32_t *offsets, uint64_t *summary, void *workspace,
                         size_t workspace_bytes, void *stream);
 size_t ldx_area_finish_workspace_bytes(uint32_t n_snps);
+int ldx_area_finish_ex_dev(ldx_hit *raw, const uint64_t *n_reserved, uint64_t hit_cap, uint32_t n_snps,
+                           ldx_hit *sorted, uint32_t *offsets, uint64_t *summary, void *workspace,
+                           size_t workspace_bytes, int counts_ready, void *stream);
+uint32_t *ldx_area_finish_counts(void *finish_workspace);   /* where the finishing step keeps its per-query counts */
 /* instrumentation: byte offset, inside the workspace of ldx_area_dev, of the uint32 count of passes (4 units of 64 rows
  * x 128 columns) the matrix-pipe band evaluated */
 size_t ldx_area_band_passes_offset(uint32_t n_snps);

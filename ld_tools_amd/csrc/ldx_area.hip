@@ -132,7 +132,7 @@ area_scan_kernel(const uint4 *__restrict__ alt, const uint4 *__restrict__ qalt, 
                  const double *__restrict__ qq, const uint32_t *__restrict__ g_begin,
                  const uint64_t *__restrict__ unit_base, uint32_t n_snps, uint32_t T, uint32_t nchunks, double n,
                  int64_t flank, int measure, double k_thres, ldx_hit *__restrict__ hits, uint64_t hit_cap,
-                 unsigned long long *__restrict__ n_hits)
+                 unsigned long long *__restrict__ n_hits, uint32_t *__restrict__ query_counts)
 {
     extern __shared__ uint4 lds[];
     uint4 *jt = lds;
@@ -207,7 +207,10 @@ area_scan_kernel(const uint4 *__restrict__ alt, const uint4 *__restrict__ qalt, 
                             }
                             if (keep) {
                                 const uint64_t s = slot + __builtin_popcountll(m & ((1ull << lane) - 1ull));
-                                if (s < hit_cap) hits[s] = ldx_hit{qrow, o, res.r_square, res.d_prime};
+                                if (s < hit_cap) {
+                                    hits[s] = ldx_hit{qrow, o, res.r_square, res.d_prime};
+                                    if (query_counts) atomicAdd(&query_counts[qrow], 1u);   // only stored hits
+                                }
                             }
                             slot += cnt;
                         }
@@ -240,8 +243,10 @@ __global__ void area_count_kernel(const ldx_hit *__restrict__ raw, const unsigne
 __global__ void __launch_bounds__(1024) area_offsets_kernel(const uint32_t *__restrict__ counts, uint32_t n_snps,
                                                             uint32_t *__restrict__ offsets, uint32_t *__restrict__ cursor,
                                                             const unsigned long long *__restrict__ n_reserved,
-                                                            unsigned long long *__restrict__ summary)
+                                                            unsigned long long *__restrict__ summary,
+                                                            uint32_t *__restrict__ n_long)
 {
+    if (threadIdx.x == 0) *n_long = 0u;   // the ordering kernels' list of long queries starts empty (no memset node)
     // Exclusive scan of the per-SNP hit counts by ONE workgroup in three barrier-separated phases per chunk of
     // 8192 x 1024 counts: (A) a wave at a time sums 1024-count tiles (every lane its own 64-byte line, the lane
     // totals reduced by shuffles), (B) the tile totals -- a table in LDS -- are scanned by the block, (C) the waves
@@ -342,6 +347,64 @@ __global__ void __launch_bounds__(1024) area_offsets_kernel(const uint32_t *__re
     }
 }
 
+// The same exclusive scan for large n in two short multi-block kernels (the single-workgroup kernel above takes 38 us at
+// 100 000 SNPs: one CU's worth of bandwidth): (1) every block of 1024 counts writes its total; (2) every block adds up the
+// totals of the blocks before it (at most a few thousand words, L2-resident), scans its own 1024 counts and writes
+// offsets and cursor; the last block writes offsets[n_snps] and the summary.
+constexpr uint32_t kScanBlock = 1024u;   // counts per block: 256 threads x 4
+
+__global__ void __launch_bounds__(256) area_block_sums_kernel(const uint32_t *__restrict__ counts, uint32_t n_snps,
+                                                              uint32_t *__restrict__ block_tot, uint32_t *__restrict__ n_long)
+{
+    __shared__ uint32_t wsum[4];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *n_long = 0u;   // the ordering kernels' list of long queries starts empty
+    const uint32_t k0 = blockIdx.x * kScanBlock + threadIdx.x * 4u;
+    uint32_t sum = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 4u; ++j) sum += k0 + j < n_snps ? counts[k0 + j] : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
+    if ((threadIdx.x & 63u) == 0) wsum[threadIdx.x >> 6] = sum;
+    block_sync();
+    if (threadIdx.x == 0) block_tot[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+__global__ void __launch_bounds__(256) area_block_scan_kernel(const uint32_t *__restrict__ counts, uint32_t n_snps,
+                                                              const uint32_t *__restrict__ block_tot,
+                                                              uint32_t *__restrict__ offsets, uint32_t *__restrict__ cursor,
+                                                              const unsigned long long *__restrict__ n_reserved,
+                                                              unsigned long long *__restrict__ summary)
+{
+    __shared__ uint32_t wsum[4], wpre[4];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    uint32_t before = 0;                                   // hits of the blocks before this one
+    for (uint32_t b = threadIdx.x; b < blockIdx.x; b += 256u) before += block_tot[b];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) before += __shfl_down(before, off);
+    if (lane == 0) wpre[wv] = before;
+    const uint32_t k0 = blockIdx.x * kScanBlock + threadIdx.x * 4u;
+    uint32_t c[4], sum = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 4u; ++j) { c[j] = k0 + j < n_snps ? counts[k0 + j] : 0u; sum += c[j]; }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(incl, off); if (lane >= (uint32_t)off) incl += y; }
+    if (lane == 63) wsum[wv] = incl;
+    block_sync();
+    uint32_t at = wpre[0] + wpre[1] + wpre[2] + wpre[3] + incl - sum;
+    for (uint32_t w = 0; w < wv; ++w) at += wsum[w];
+#pragma unroll
+    for (uint32_t j = 0; j < 4u; ++j) {
+        if (k0 + j < n_snps) { offsets[k0 + j] = at; cursor[k0 + j] = at; }
+        at += c[j];
+    }
+    if (blockIdx.x == gridDim.x - 1u && threadIdx.x == 255u) {   // the last thread of the last block holds the grand total
+        offsets[n_snps] = at;
+        summary[0] = at;
+        summary[1] = *n_reserved;
+    }
+}
+
 __global__ void area_scatter_kernel(const ldx_hit *__restrict__ raw, const unsigned long long *__restrict__ n_reserved,
                                     uint64_t cap, uint32_t n_snps, uint32_t *__restrict__ cursor, ldx_hit *__restrict__ sorted)
 {
@@ -432,6 +495,16 @@ extern "C" int ldx_area_finish_dev(ldx_hit *raw, const uint64_t *n_reserved, uin
                                    ldx_hit *sorted, uint32_t *offsets, uint64_t *summary, void *workspace,
                                    size_t workspace_bytes, void *stream)
 {
+    return ldx_area_finish_ex_dev(raw, n_reserved, hit_cap, n_snps, sorted, offsets, summary, workspace, workspace_bytes, 0,
+                                  stream);
+}
+
+extern "C" uint32_t *ldx_area_finish_counts(void *finish_workspace) { return (uint32_t *)finish_workspace; }
+
+extern "C" int ldx_area_finish_ex_dev(ldx_hit *raw, const uint64_t *n_reserved, uint64_t hit_cap, uint32_t n_snps,
+                                      ldx_hit *sorted, uint32_t *offsets, uint64_t *summary, void *workspace,
+                                      size_t workspace_bytes, int counts_ready, void *stream)
+{
     LDX_REQUIRE(n_reserved && offsets && summary && workspace, "null pointer");
     LDX_REQUIRE((raw && sorted) || hit_cap == 0, "hit buffers are null but hit_cap > 0");
     LDX_REQUIRE(n_snps >= 1 && hit_cap < (1ull << 32), "bad shape");
@@ -442,15 +515,25 @@ extern "C" int ldx_area_finish_dev(ldx_hit *raw, const uint64_t *n_reserved, uin
     const size_t vec = (((size_t)n_snps + 1u) * 4u + 255u) / 256u * 256u;
     uint32_t *counts = (uint32_t *)workspace, *cursor = (uint32_t *)((char *)workspace + vec);
     uint32_t *n_long = (uint32_t *)((char *)workspace + 2u * vec), *long_list = n_long + 1;   // [1 + n_snps]
-    LDX_HIP(hipMemsetAsync(counts, 0, ((size_t)n_snps + 1u) * 4u, s));
-    LDX_HIP(hipMemsetAsync(n_long, 0, sizeof(uint32_t), s));
+    // counts_ready: the scan counted the hits per query row as it stored them (ldx_area_scan_dev with
+    // query_counts = ldx_area_finish_counts(workspace)): no memset, no pass over the slot buffer
+    if (!counts_ready) LDX_HIP(hipMemsetAsync(counts, 0, ((size_t)n_snps + 1u) * 4u, s));
     const uint32_t slot_blocks = (uint32_t)((hit_cap + 255u) / 256u);
-    if (slot_blocks) {
+    if (slot_blocks && !counts_ready) {
         area_count_kernel<<<slot_blocks, 256, 0, s>>>(raw, (const unsigned long long *)n_reserved, hit_cap, n_snps, counts);
         LDX_HIP(hipGetLastError());
     }
-    area_offsets_kernel<<<1, 1024, 0, s>>>(counts, n_snps, offsets, cursor, (const unsigned long long *)n_reserved,
-                                           (unsigned long long *)summary);
+    const uint32_t scan_blocks = (n_snps + kScanBlock - 1u) / kScanBlock;
+    if (scan_blocks >= 8u && scan_blocks <= n_snps) {   // block totals live behind the list of long queries (n_snps + 1 words: never full)
+        uint32_t *block_tot = long_list + (n_snps - scan_blocks);
+        area_block_sums_kernel<<<scan_blocks, 256, 0, s>>>(counts, n_snps, block_tot, n_long);
+        LDX_HIP(hipGetLastError());
+        area_block_scan_kernel<<<scan_blocks, 256, 0, s>>>(counts, n_snps, block_tot, offsets, cursor,
+                                                          (const unsigned long long *)n_reserved, (unsigned long long *)summary);
+    } else {
+        area_offsets_kernel<<<1, 1024, 0, s>>>(counts, n_snps, offsets, cursor, (const unsigned long long *)n_reserved,
+                                               (unsigned long long *)summary, n_long);
+    }
     LDX_HIP(hipGetLastError());
     if (slot_blocks) {
         area_scatter_kernel<<<slot_blocks, 256, 0, s>>>(raw, (const unsigned long long *)n_reserved, hit_cap, n_snps, cursor,
@@ -501,6 +584,15 @@ extern "C" int ldx_area_dev(const void *alt, const double *fa, const double *fr,
                             int64_t flank, int measure, double thres, ldx_hit *hits, uint64_t hit_cap,
                             uint64_t *n_hits, void *workspace, size_t workspace_bytes, void *stream)
 {
+    return ldx_area_scan_dev(alt, fa, fr, q, n_snps, n_hap, positions, queries, n_query, flank, measure, thres, hits, hit_cap,
+                             n_hits, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int ldx_area_scan_dev(const void *alt, const double *fa, const double *fr, const double *q, uint32_t n_snps,
+                            uint32_t n_hap, const int64_t *positions, const uint32_t *queries, uint32_t n_query,
+                            int64_t flank, int measure, double thres, ldx_hit *hits, uint64_t hit_cap,
+                            uint64_t *n_hits, uint32_t *query_counts, void *workspace, size_t workspace_bytes, void *stream)
+{
     LDX_REQUIRE(alt && fa && fr && q && positions && queries && n_hits && workspace, "null pointer");
     LDX_REQUIRE(hits || hit_cap == 0, "hits is null but hit_cap > 0");
     LDX_REQUIRE(n_snps >= 1 && n_hap >= 1 && n_query >= 1 && flank >= 0, "bad shape");
@@ -515,11 +607,12 @@ extern "C" int ldx_area_dev(const void *alt, const double *fa, const double *fr,
     LDX_REQUIRE(workspace_bytes >= need && workspace_bytes >= area_mfma_workspace_bytes(n_snps),
                 "workspace too small (see ldx_area_workspace_bytes)");
     hipStream_t s = (hipStream_t)stream;
+    if (query_counts) LDX_HIP(hipMemsetAsync(query_counts, 0, ((size_t)n_snps + 1u) * 4u, s));
     const int path = g_area_path.load(std::memory_order_relaxed);
     if (path == LDX_PATH_MFMA || path == LDX_PATH_FP4 ||
         (path == LDX_PATH_AUTO && (uint64_t)n_query * 16u >= n_snps && n_snps >= 2)) {
         const int rc = area_mfma(alt, fa, fr, q, n_snps, n_hap, positions, queries, n_query, flank, measure, thres, hits, hit_cap,
-                                 n_hits, workspace, path != LDX_PATH_MFMA, s);
+                                 n_hits, query_counts, workspace, path != LDX_PATH_MFMA, s);
         if (rc != ldx::kNoSlot) return rc;
         if (path != LDX_PATH_AUTO) return LDX_E_UNSUPPORTED;
         // AUTO and no ticket-counter slot for this stream: the popcount scan below finds the very same hits
@@ -537,7 +630,7 @@ extern "C" int ldx_area_dev(const void *alt, const double *fa, const double *fr,
     area_scan_kernel<<<cus, kThreads, lds, s>>>((const uint4 *)alt, w.qalt, fa, fr, positions, w.qpos, w.qrow, w.qfa,
                                                 w.qfr, w.qq, w.g_begin, w.unit_base, n_snps, T, nch, (double)n_hap,
                                                 flank, measure, thres_to_k(thres), hits, hit_cap,
-                                                (unsigned long long *)n_hits);
+                                                (unsigned long long *)n_hits, query_counts);
     LDX_HIP(hipGetLastError());
     return LDX_OK;
 }

@@ -50,7 +50,8 @@ int triangle_mfma(const void *alt, const double *fa, const double *fr, const dou
 size_t area_mfma_workspace_bytes(uint32_t n_snps);
 int area_mfma(const void *alt, const double *fa, const double *fr, const double *q, uint32_t n_snps, uint32_t n_hap,
               const int64_t *positions, const uint32_t *queries, uint32_t n_query, int64_t flank, int measure, double thres,
-              ldx_hit *hits, uint64_t hit_cap, uint64_t *n_hits, void *workspace, bool fp4, hipStream_t s);
+              ldx_hit *hits, uint64_t hit_cap, uint64_t *n_hits, uint32_t *query_counts, void *workspace, bool fp4,
+              hipStream_t s);
 
 #define LDX_HIP(call)                                                                       \
     do {                                                                                    \

@@ -203,11 +203,12 @@ static std::atomic<int> g_forced_short{-1};   // >= 0: number of halved passes p
 // hits, (query = row, opposing = column) and (query = column, opposing = row)  (ld_area.py:152-276).
 struct AreaArgs {
     const int64_t *pos;            // [n_snps] ascending 1-based positions
-    const uint8_t *is_query;       // [n_snps] 1 = the SNP is a query
+    const uint8_t *is_query;       // [n_snps] 1 = the SNP is a query; null = every SNP is
     const uint32_t *pass_base;     // [T + 1] prefix sum of passes per j-tile (pass_base[T] = all passes)
     const uint32_t *g_begin;       // [T] first 64-row group of tile t that can hold a hit (2t unless the queries end before the tile)
     const uint32_t *g_end;         // [T] one past the last such group
     ldx_hit *hits;
+    uint32_t *counts;              // [n_snps] or null: hits per query row, counted as they are appended (ldx_area_scan_dev)
     unsigned long long *n_hits;
     uint64_t hit_cap;
     double flank, k_thres;
@@ -572,7 +573,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                     d2 *dst = reinterpret_cast<d2 *>(cstat + tid * kStat);
                     dst[0] = d2{c.a, c.ra};
                     dst[1] = d2{c.rr, c.rq};
-                    if (kArea) dst[2] = j < n_snps ? d2{(double)aa.pos[j], (double)aa.is_query[j]} : d2{0.0, 0.0};
+                    if (kArea) dst[2] = j < n_snps ? d2{(double)aa.pos[j], (double)(aa.is_query ? aa.is_query[j] : (uint8_t)1)} : d2{0.0, 0.0};
                     if constexpr (kF32Tier) {
                         const F32Col c32 = f32_col(c.a, c.ra, c.rr, !odd);
                         *reinterpret_cast<v4f *>(ctab32 + tid * 4u) = v4f{c32.a, c32.ra, c32.rr, c32.s};
@@ -592,7 +593,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                     const F32Row r32 = f32_row(r.a_s * 1e-4, r.ra, r.rr, row_ordinary);   // 1e4 a / 1e4: exact (a < 2^32)
                     *reinterpret_cast<v4f *>(rtab32 + lane * 4u) = v4f{r32.a, r32.ra_s, r32.rr_s, r32.s};
                 }
-                if (kArea) dst[2] = i < n_snps ? d2{(double)aa.pos[i], (double)aa.is_query[i]} : d2{0.0, 0.0};
+                if (kArea) dst[2] = i < n_snps ? d2{(double)aa.pos[i], (double)(aa.is_query ? aa.is_query[i] : (uint8_t)1)} : d2{0.0, 0.0};
             }
             if (ktok && tid == 0)   // one workgroup per CU in its K loop at a time (see g_sched)
                 while (atomicCAS(ktok, 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(4);
@@ -1069,7 +1070,10 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                     }
                     if (keep) {
                         const uint64_t sl = slot + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
-                        if (sl < aa.hit_cap) aa.hits[sl] = ldx_hit{qrow, orow, v.r_square, v.d_prime};
+                        if (sl < aa.hit_cap) {
+                            aa.hits[sl] = ldx_hit{qrow, orow, v.r_square, v.d_prime};
+                            if (aa.counts) atomicAdd(&aa.counts[qrow], 1u);   // only stored hits: what the scatter will place
+                        }
                     }
                     slot += cnt;
                 };
@@ -1439,12 +1443,13 @@ __global__ void area_mask_kernel(const uint32_t *__restrict__ queries, uint32_t 
 __global__ void __launch_bounds__(1024) area_band_plan_kernel(const int64_t *__restrict__ pos, uint32_t n_snps, uint32_t T,
                                                               int64_t flank, const uint32_t *__restrict__ queries,
                                                               uint32_t n_query, uint32_t *__restrict__ g_begin,
-                                                              uint32_t *__restrict__ g_end, uint32_t *__restrict__ pass_base)
+                                                              uint32_t *__restrict__ g_end, uint32_t *__restrict__ pass_base,
+                                                              unsigned long long *__restrict__ n_hits)
 {
     const uint32_t qmin = queries[0], qmax = queries[n_query - 1u];
     __shared__ uint32_t carry;
     __shared__ uint32_t wsum[16];
-    if (threadIdx.x == 0) { carry = 0; pass_base[0] = 0; }
+    if (threadIdx.x == 0) { carry = 0; pass_base[0] = 0; *n_hits = 0ull; }   // (the slot counter of the scan that follows: no memset node)
     block_sync();
     for (uint32_t t0 = 0; t0 < T; t0 += 1024u) {
         const uint32_t t = t0 + threadIdx.x;
@@ -1490,7 +1495,7 @@ size_t area_mfma_workspace_bytes(uint32_t n_snps)
 
 int area_mfma(const void *alt, const double *fa, const double *fr, const double *q, uint32_t n_snps, uint32_t n_hap,
               const int64_t *positions, const uint32_t *queries, uint32_t n_query, int64_t flank, int measure, double thres,
-              ldx_hit *hits, uint64_t hit_cap, uint64_t *n_hits, void *workspace, bool fp4, hipStream_t s)
+              ldx_hit *hits, uint64_t hit_cap, uint64_t *n_hits, uint32_t *query_counts, void *workspace, bool fp4, hipStream_t s)
 {
     const uint32_t T = n_slabs(n_snps), nch = n_chunks(n_hap);
     char *w = (char *)workspace;
@@ -1501,11 +1506,15 @@ int area_mfma(const void *alt, const double *fa, const double *fr, const double 
     uint32_t *g_end = (uint32_t *)w;
     w += ((size_t)T * 4u + 255u) / 256u * 256u;
     uint32_t *g_begin = (uint32_t *)w;
-    LDX_HIP(hipMemsetAsync(n_hits, 0, sizeof(uint64_t), s));
-    LDX_HIP(hipMemsetAsync(is_query, 0, n_snps, s));
-    area_mask_kernel<<<(n_query + 255u) / 256u, 256, 0, s>>>(queries, n_query, is_query);
-    LDX_HIP(hipGetLastError());
-    area_band_plan_kernel<<<1, 1024, 0, s>>>(positions, n_snps, T, flank, queries, n_query, g_begin, g_end, pass_base);
+    if (n_query == n_snps) {   // ascending distinct rows: every SNP is a query -- no mask at all
+        is_query = nullptr;
+    } else {
+        LDX_HIP(hipMemsetAsync(is_query, 0, n_snps, s));
+        area_mask_kernel<<<(n_query + 255u) / 256u, 256, 0, s>>>(queries, n_query, is_query);
+        LDX_HIP(hipGetLastError());
+    }
+    area_band_plan_kernel<<<1, 1024, 0, s>>>(positions, n_snps, T, flank, queries, n_query, g_begin, g_end, pass_base,
+                                             (unsigned long long *)n_hits);
     LDX_HIP(hipGetLastError());
     const size_t lds = mfma_lds_bytes(kRows64, false);
     const int cus = device_cus();
@@ -1518,6 +1527,7 @@ int area_mfma(const void *alt, const double *fa, const double *fr, const double 
     aa.g_begin = g_begin;
     aa.g_end = g_end;
     aa.hits = hits;
+    aa.counts = query_counts;
     aa.n_hits = (unsigned long long *)n_hits;
     aa.hit_cap = hit_cap;
     aa.flank = (double)flank;

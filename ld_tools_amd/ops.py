@@ -288,9 +288,50 @@ class AreaHits:
         return [tuple(x) for x in out]
 
 
+class _AreaPlan:
+    """Buffers of one ld_area call shape (panel, positions tensor, queries, flank, measure, threshold) and -- once the
+    shape has been seen twice -- the HIP graph of its launches (query mask, band plan, scan, offsets, scatter, ordering:
+    ten small launches around one 0.36 ms kernel, launch-bound when issued one by one)."""
+
+    def __init__(self, panel, nq, cap):
+        dev = panel.device
+        self.cap = cap
+        self.ws_bytes = lib.ldx_area_workspace_bytes(panel.n_snps, panel.n_hap, nq)
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
+        self.fin_bytes = lib.ldx_area_finish_workspace_bytes(panel.n_snps)
+        self.fin = torch.empty(self.fin_bytes, dtype=torch.uint8, device=dev)
+        self.n_hits = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.summary = torch.zeros(2, dtype=torch.int64, device=dev)
+        self.offsets = torch.empty(panel.n_snps + 1, dtype=torch.int32, device=dev)
+        self.raw = torch.empty((cap, 4), dtype=torch.int32, device=dev)      # ldx_hit = {u32, u32, f32, f32}
+        self.hits = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+        self.graph = None
+        self.uses = 0
+
+
+def _area_launch(panel, pos, q, nq, flank, measure, thres, plan, events=None):
+    """The launches of one scan + finish on torch's current stream (no host synchronisation)."""
+    if events is not None:
+        del events[:]
+        events.extend(torch.cuda.Event(enable_timing=True) for _ in range(3))
+        events[0].record()
+    counts = lib.ldx_area_finish_counts(plan.fin.data_ptr())     # the scan counts per query row as it stores the hits
+    check(lib.ldx_area_scan_dev(panel.alt.data_ptr(), panel.fa.data_ptr(), panel.fr.data_ptr(), panel.q.data_ptr(),
+                                panel.n_snps, panel.n_hap, pos.data_ptr(), q.data_ptr(), nq, int(flank),
+                                MEASURES[measure], float(thres), plan.raw.data_ptr(), plan.cap, plan.n_hits.data_ptr(),
+                                counts, plan.ws.data_ptr(), plan.ws_bytes, _stream_ptr()), "ldx_area_scan_dev")
+    if events is not None:
+        events[1].record()
+    check(lib.ldx_area_finish_ex_dev(plan.raw.data_ptr(), plan.n_hits.data_ptr(), plan.cap, panel.n_snps,
+                                     plan.hits.data_ptr(), plan.offsets.data_ptr(), plan.summary.data_ptr(),
+                                     plan.fin.data_ptr(), plan.fin_bytes, 1, _stream_ptr()), "ldx_area_finish_ex_dev")
+    if events is not None:
+        events[2].record()
+
+
 def ld_area(panel: PackedPanel, positions, queries: Optional[Sequence[int]] = None, flank: int = 100000,
             measure: str = "r_square", thres: float = 0.8, hit_capacity: Optional[int] = None,
-            check_positions: bool = True, events: Optional[list] = None) -> AreaHits:
+            check_positions: bool = True, events: Optional[list] = None, use_graph: Optional[bool] = None) -> AreaHits:
     """Windowed scan of ld_area.py:152-276 over the panel.
 
     positions: ascending 1-based coordinates of the panel's SNPs (VCF order).  queries: panel
@@ -299,14 +340,21 @@ def ld_area(panel: PackedPanel, positions, queries: Optional[Sequence[int]] = No
     ld_area.py:174-177,215-217); var_1 = query, var_2 = opposing; kept when the rounded
     ``measure`` >= thres (ld_area.py:248).
 
-    Everything up to the ordered hit list runs on the device (scan -> count per query -> scan -> scatter -> per-query
-    order: ldx_area_dev + ldx_area_finish_dev); the host reads two integers at the end to size the result.
+    Everything up to the ordered hit list runs on the device (scan, which counts per query as it stores -> exclusive scan
+    -> scatter -> per-query order: ldx_area_scan_dev + ldx_area_finish_ex_dev); the host reads two integers at the end
+    to size the result.  When the same scan shape comes again -- the same panel, the same DEVICE tensor of positions,
+    the same queries / flank / measure / threshold: a driver walking tables of one chromosome -- its launches are
+    replayed as ONE HIP graph from the second repetition on (``use_graph``: None = that rule, False = never, True = from the
+    first call); the plan (buffers + graph) lives on the panel.
     ``events`` (instrumentation, bench.py): a list that receives three torch events of the current stream -- before the
-    scan, between the scan (ldx_area_dev: mask, band plan, band kernel) and the finishing kernels, after them.
+    scan, between the scan and the finishing kernels, after them; forces eager launches.
     """
     dev = panel.device
+    pos_key = None
     if isinstance(positions, torch.Tensor):
         pos = positions.to(dev, dtype=torch.int64).contiguous()
+        if pos.data_ptr() == positions.data_ptr():
+            pos_key = (pos.data_ptr(), int(pos.numel()))
         # a device tensor is checked on the device (one more host round trip); callers that scan one chromosome many
         # times pass check_positions=False after the first call
         if check_positions and pos.numel() > 1 and bool((pos[1:] < pos[:-1]).any().item()):
@@ -318,8 +366,13 @@ def ld_area(panel: PackedPanel, positions, queries: Optional[Sequence[int]] = No
         pos = torch.as_tensor(pos_h).to(dev)
     if pos.numel() != panel.n_snps:
         raise _lib.LdxError("positions must have one entry per SNP")
+    plans = panel.__dict__.setdefault("_area_plans", {})
+    q_key = None
     if queries is None:
-        q = torch.arange(panel.n_snps, dtype=torch.int32, device=dev)
+        q = plans.get("all_rows")
+        if q is None:
+            q = plans["all_rows"] = torch.arange(panel.n_snps, dtype=torch.int32, device=dev)
+        q_key = "all"
     else:
         qn = np.sort(np.asarray(queries, dtype=np.int64))   # the kernel wants ascending rows
         if qn.size == 0:
@@ -330,40 +383,50 @@ def ld_area(panel: PackedPanel, positions, queries: Optional[Sequence[int]] = No
             raise _lib.LdxError("query row out of range")
         q = torch.as_tensor(qn.astype(np.int32)).to(dev)
     nq = int(q.numel())
-    ws_bytes = lib.ldx_area_workspace_bytes(panel.n_snps, panel.n_hap, nq)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    fin_bytes = lib.ldx_area_finish_workspace_bytes(panel.n_snps)
-    fin = torch.empty(fin_bytes, dtype=torch.uint8, device=dev)
-    n_hits = torch.zeros(1, dtype=torch.int64, device=dev)
-    summary = torch.zeros(2, dtype=torch.int64, device=dev)
-    offsets = torch.empty(panel.n_snps + 1, dtype=torch.int32, device=dev)
     cap = int(hit_capacity) if hit_capacity is not None else max(1 << 20, 16 * nq)   # slots (16 B each); an overflow re-runs with the exact count
+    # the plan of this call shape (only shapes that can come again unchanged have one that is kept)
+    key = None
+    if pos_key is not None and q_key is not None and events is None and use_graph is not False:
+        key = (pos_key, q_key, int(flank), measure, float(thres), get_area_path(), panel.alt.data_ptr())
+    plan = plans.get(key) if key is not None else None
+    if plan is not None and plan.cap < cap:
+        plan = None
     while True:
-        raw = torch.empty((cap, 4), dtype=torch.int32, device=dev)      # ldx_hit = {u32, u32, f32, f32}
-        hits = torch.empty((cap, 4), dtype=torch.int32, device=dev)
-        if events is not None:
-            del events[:]
-            events.extend(torch.cuda.Event(enable_timing=True) for _ in range(3))
-            events[0].record()
-        check(lib.ldx_area_dev(panel.alt.data_ptr(), panel.fa.data_ptr(), panel.fr.data_ptr(), panel.q.data_ptr(),
-                               panel.n_snps, panel.n_hap, pos.data_ptr(), q.data_ptr(), nq, int(flank),
-                               MEASURES[measure], float(thres), raw.data_ptr(), cap, n_hits.data_ptr(),
-                               ws.data_ptr(), ws_bytes, _stream_ptr()), "ldx_area_dev")
-        if events is not None:
-            events[1].record()
-        check(lib.ldx_area_finish_dev(raw.data_ptr(), n_hits.data_ptr(), cap, panel.n_snps, hits.data_ptr(),
-                                      offsets.data_ptr(), summary.data_ptr(), fin.data_ptr(), fin_bytes,
-                                      _stream_ptr()), "ldx_area_finish_dev")
-        if events is not None:
-            events[2].record()
-        total, reserved = (int(x) for x in summary.tolist())             # the one host round trip
-        if reserved <= cap:
+        if plan is None:
+            plan = _AreaPlan(panel, nq, cap)
+            if key is not None:
+                if len(plans) > 8:                  # a handful of shapes per panel; drop the oldest beyond that
+                    for k in [k for k in plans if k != "all_rows"][:len(plans) - 8]:
+                        del plans[k]
+                plans[key] = plan
+        plan.uses += 1
+        if key is not None and plan.graph is None and (use_graph or plan.uses >= 2) and \
+                not torch.cuda.is_current_stream_capturing():
+            try:                                    # capture the launches once; a failure leaves the eager path
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    _area_launch(panel, pos, q, nq, flank, measure, thres, plan)
+                plan.graph = g
+            except Exception:                       # noqa: BLE001
+                plan.graph = False
+                torch.cuda.synchronize()
+        if plan.graph:
+            plan.graph.replay()
+        else:
+            _area_launch(panel, pos, q, nq, flank, measure, thres, plan, events)
+        total, reserved = (int(x) for x in plan.summary.tolist())             # the one host round trip
+        if reserved <= plan.cap:
             break
         cap = reserved + 4096            # the count is exact for a re-run: one retry suffices
-    hits = hits[:total]
-    qrow = hits[:, 0].to(torch.int64) & 0xFFFFFFFF
-    orow = hits[:, 1].to(torch.int64) & 0xFFFFFFFF
+        if key is not None:
+            plans.pop(key, None)
+        plan = None
+    hits = plan.hits[:total]
+    rows = hits[:, 0:2].to(torch.int64) & 0xFFFFFFFF        # both row columns in one pass (two small kernels, not four)
+    qrow, orow = rows[:, 0], rows[:, 1]
     ld32 = hits[:, 2:4].contiguous().view(torch.float32)
+    offsets = plan.offsets.clone() if key is not None else plan.offsets     # a kept plan's buffers are overwritten by the next call
 
     def count_pairs() -> int:
         # pairs evaluated = sum over queries of window population (bookkeeping, on device, only when asked for)
@@ -376,7 +439,8 @@ def ld_area(panel: PackedPanel, positions, queries: Optional[Sequence[int]] = No
     band = None
     if get_area_path() != "popcount" and (get_area_path() != "auto" or (nq * 16 >= panel.n_snps and panel.n_snps >= 2)):
         off = lib.ldx_area_band_passes_offset(panel.n_snps)
-        band = lambda: int(ws[off:off + 4].view(torch.int32).item())    # noqa: E731
+        word = plan.ws[off:off + 4].clone() if key is not None else plan.ws[off:off + 4]   # a kept plan is overwritten by the next call
+        band = lambda: int(word.view(torch.int32).item())    # noqa: E731
     return AreaHits(qrow, orow, ld32, count_pairs, offsets, band)
 
 
