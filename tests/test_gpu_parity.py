@@ -716,6 +716,49 @@ def test_triangle_half_height_tickets_agree(gpu, path):
             assert torch.equal(a, got[0][0]) and torch.equal(b, got[0][1])
 
 
+def test_fp32_tier_parks_the_rows_and_columns_of_odd_snps(gpu):
+    """Round 4: a SNP that is not ordinary (monomorphic ALT / REF, all missing, some missing codes) parks its own row /
+    column of lane-steps in the fp32 tier instead of sending the whole unit to the fp64 epilogue.  Panels with one, a few
+    and MANY such SNPs per tile (the last overflows the per-wave queue: the unit is redone whole) through the product
+    variant of the FP4 kernel -- interior units only exist from ~400 SNPs on -- against the popcount kernel, both cell
+    formats, and a band of rows against the C oracle."""
+    import torch
+    from ld_tools_amd import PackedPanel, ld_triangle, synth
+    from oracle import c_oracle
+
+    n, h = 1500, 1008
+    rng = np.random.RandomState(11)
+    for n_odd in (1, 6, 40, 400):
+        codes = synth.synth_codes_host(n, h, seed=5 + n_odd, miss=0.0)
+        rows = rng.choice(n, size=n_odd, replace=False)
+        for k, r in enumerate(rows):
+            kind = k % 4
+            if kind == 0:
+                codes[r] = 0                                   # monomorphic REF
+            elif kind == 1:
+                codes[r] = 1                                   # monomorphic ALT
+            elif kind == 2:
+                codes[r, ::7] = 2                              # missing codes: a + r < n
+            else:
+                codes[r] = 2                                   # nothing but missing codes
+        p = PackedPanel.from_codes(codes)
+        for fmt in ("k16", "ld32"):
+            got = ld_triangle(p, fmt=fmt, path="fp4")          # no side outputs: the fp32 tier + its fallbacks
+            want = ld_triangle(p, fmt=fmt, path="popcount")
+            view = torch.int16 if fmt == "k16" else torch.int32
+            assert torch.equal(got.cells.view(view), want.cells.view(view)), (n_odd, fmt)
+        o = c_oracle.Panel(codes)
+        r0 = int(rows[0]) if rows[0] > 0 else 1
+        t = o.triangle(r0, r0 + 1, libm_pow=True)
+        cols = np.arange(r0, dtype=np.int64)
+        res = ld_triangle(p, fmt="k16", path="fp4")
+        kk, int0, esc = res.k_and_int0(res.cell_index(np.full(r0, r0), cols))
+        want_k = np.stack([np.rint(t["rsq_rnd"][r0, :r0] * 1e4), np.rint(t["dp_rnd"][r0, :r0] * 1e4)], axis=1)
+        ok = ~esc
+        assert np.array_equal(kk[ok], want_k[ok].astype(np.int64)), n_odd
+        assert np.array_equal(int0[:, 0], (t["flags"][r0, :r0] & 2) != 0) and np.array_equal(int0[:, 1], (t["flags"][r0, :r0] & 1) != 0)
+
+
 def test_triangle_on_many_streams(gpu):
     """The pass scheduler keeps one ticket-counter pair per stream in a pool of 256: more streams than that, used one
     after another and two at a time, still give the single-stream result."""
@@ -999,6 +1042,48 @@ def test_area_hits_beyond_the_float_cell(gpu, area_path):
         k = [i for i, (a, b) in enumerate(zip(hq, ho)) if (a, b) == (1, 0)]
         assert len(k) == 1 and vals[k[0]] == (4080.4507, 4948.0)
         assert np.isnan(hits.ld32.cpu().numpy()[k[0]]).all()
+
+
+def test_area_repeated_calls_replay_a_graph_and_stay_correct(gpu):
+    """Round 4: ld_area keeps a plan per call shape on the panel (buffers + from the second repetition on ONE HIP graph of
+    its launches).  Repeated calls with a DEVICE tensor of positions and every SNP a query -- the shape a driver repeats --
+    return the popcount scan's hits every time, also when shapes alternate (two thresholds, two flanks), when the first hit
+    buffer is too small (the overflow retry re-plans), and a result handed out earlier is not overwritten by a later call."""
+    import torch
+    from ld_tools_amd import PackedPanel, ld_area, ops, synth
+
+    n, h = 6000, 1008
+    p = PackedPanel.from_codes(synth.synth_codes_device(n, h, seed=21))
+    pos = torch.as_tensor(synth.synth_positions(n, step=500)).to(p.device)
+    shapes = [(20000, "r_square", 0.8), (20000, "r_square", 0.3), (60000, "d_prime", 0.95)]
+    want = {}
+    old = ops.get_area_path()
+    try:
+        ops.set_area_path("popcount")
+        for sh in shapes:
+            want[sh] = ld_area(p, pos, None, *sh, use_graph=False)
+    finally:
+        ops.set_area_path(old)
+
+    def same(a, b):
+        return len(a) == len(b) and torch.equal(a.query, b.query) and torch.equal(a.oppos, b.oppos) and \
+            torch.equal(a.ld32.view(torch.int32), b.ld32.view(torch.int32)) and torch.equal(a.offsets, b.offsets)
+
+    kept = []
+    for rep in range(4):
+        for sh in shapes:
+            got = ld_area(p, pos, None, *sh, check_positions=False)
+            assert same(got, want[sh]), (rep, sh)
+            kept.append((sh, got))
+    for sh, got in kept:                                    # earlier results are their own tensors, not views of a plan
+        assert same(got, want[sh]), sh
+    plans = [v for k, v in p._area_plans.items() if k != "all_rows"]
+    assert len(plans) == len(shapes) and all(pl.graph for pl in plans), "every repeated shape should have its graph by now"
+    assert want[shapes[1]].band_passes is None and kept[1][1].band_passes > 0
+    # a hit buffer that is too small: the retry takes the exact count and the next call replays the larger plan
+    small = ld_area(p, pos, None, 20000, "r_square", 0.05, hit_capacity=4096, check_positions=False)
+    again = ld_area(p, pos, None, 20000, "r_square", 0.05, hit_capacity=4096, check_positions=False)
+    assert len(small) > 4096 and same(small, again)
 
 
 def test_area_rejects_unsorted_positions(gpu):
