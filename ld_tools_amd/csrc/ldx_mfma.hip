@@ -369,7 +369,28 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
     uint32_t *ulist = reinterpret_cast<uint32_t *>(ctab32 + kSlab * 4u + kMfmaWaves * kRows64 * 4u) + kMfmaWaves * kQueueCap * 9u +
                       wave * 64u;   // [64]: parked pairs deferred to the mirror batch (entry << 3 | pair)
     const F32Const fc32 = aa.f32;   // computed on the host (f32_const): kernel arguments live in scalar registers
-    auto draw = [&]() { return atomicAdd(&sched[0], 1u); };
+    // The band (ld_area) hands its passes out PER XCD: the pass list -- j-tile-major, i.e. sorted by position -- is cut into
+    // eight contiguous ranges, one per XCD, each with its own counter (sched[2 + 32 x]: the K-loop-token words, which the
+    // band never uses; a cache line apart); a workgroup draws from the range of the XCD it runs on and, when that is
+    // exhausted, from the next ones.  The +-flank windows of consecutive tiles overlap almost entirely, so an XCD that
+    // walks a contiguous stretch of tiles finds their rows in its own 4 MiB L2 instead of re-streaming them from the
+    // Infinity Cache (round 3: 450 MB of traffic for a 64 MB plane).  The triangle keeps the single counter: every one of its
+    // tiles needs all rows below it, which no L2 holds.
+    const uint32_t my_xcd = kArea ? (__builtin_amdgcn_s_getreg(63508) & 7u) : 0u;   // XCC_ID
+    auto draw = [&]() -> uint32_t {
+        if constexpr (kArea) {
+            for (uint32_t k = 0; k < 8u; ++k) {
+                const uint32_t x = (my_xcd + k) & 7u;
+                const uint32_t lo = (uint32_t)((uint64_t)n_tickets * x / 8u), hi = (uint32_t)((uint64_t)n_tickets * (x + 1u) / 8u);
+                if (lo == hi) continue;
+                const uint32_t got = atomicAdd(&sched[2u + 32u * x], 1u);
+                if (got < hi - lo) return lo + got;
+            }
+            return n_tickets;   // every range is exhausted
+        } else {
+            return atomicAdd(&sched[0], 1u);
+        }
+    };
     // this CU's K-loop token: OFF in product builds.  Tuning builds switch it on with LDX_ABLATE bit 4096 to make the
     // stamps readable (K loop alone on the matrix pipe: 29.3k cycles per unit).  It buys nothing on the wall clock: the
     // two waves of a SIMD are bound by their combined instruction issue.
@@ -391,6 +412,8 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
             if (tid == 0 && atomicAdd(&sched[1], 1u) == gridDim.x - 1u) {
                 sched[1] = 0u;
                 sched[kSchedDone] = aa.launch_seq;   // the host may hand an idle slot to another stream (acquire_sched)
+                if (kArea)
+                    for (uint32_t x = 0; x < 8u; ++x) sched[2u + 32u * x] = 0u;   // the per-XCD counters (over-drawn at the end)
                 __threadfence();
                 sched[0] = 0u;
             }
