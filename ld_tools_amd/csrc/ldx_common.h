@@ -387,8 +387,10 @@ __device__ __forceinline__ void ld_multi_fast2(const T (&cnt_scaled)[W], const F
 // the step was bound by its store instructions, not its arithmetic): tools/probes/epi.hip, profiles/r04/fp32_tier_*.log.
 //
 // Error budget (u = 2^-24; every table entry is a double-precision value rounded once to float32):
-//   Dn = n c - a1 a2 is computed exactly while |Dn| < 2^24 (p = fl(a1 a2), e = a1 a2 - p exactly by fma,
-//        v = fl(n c - p) is exact there, v - e too); beyond it two roundings: (1 + 2u);
+//   Dn = n c - a1 a2 is computed exactly while |Dn| < 2^24 (n <= 4096: p = a1 a2 is exact; n > 4096, the kernel's form since
+//        round 4: the column count split a2 = ah + al, f32_split_a below, p = a1 ah exact, fma(c, n, -p) and fma(-a1, al, .)
+//        exact; the error-free product p = fl(a1 a2), e = a1 a2 - p by fma, (fl(n c - p)) - e, is kept as the third
+//        instantiation); beyond 2^24 two roundings: (1 + 2u);
 //   y_r = ((Dn s1) s2)^2, s = 10 / sqrt(a r): rel. error <= 13u;   y_d = |Dn| max(ra1s x, rr1s y): rel. error <= 6u;
 //   the reference's own deviation from the exact rational value, in y units: <= 6e-12 n^2 / B <= 6e-12 n^2 for D'
 //   and <= 1.2e-11 n^2 |Dn| / (a1 r1 a2 r2) <= 1.2e-11 n^2 / (n - 1) for r^2 (the fp64 tier's bounds with B >= 1 and
@@ -453,15 +455,30 @@ __device__ __forceinline__ float f32_k_to_value(float k)
 // Dn = fl(n c - p) is exact in one fma -- two instructions per pair less (of 24).
 __host__ __device__ inline bool f32_small_n(double n) { return n <= 4096.0; }
 
-template <int W, typename Cell, bool kSmallN = false>
+// The column count split for n > 4096 (f32_split_a): a2 = ah + al with al = a2 mod 16, so that a1 * ah has at most 24
+// significant bits (a1 < 2^14: LDX_MAX_HAPS) and is EXACT in float32; then q = fma(c, n, -a1 ah) = Dn + a1 al is an integer
+// below 2^24 (exact) and Dn = fma(-a1, al, q) too: three instructions where the error-free product needs four.  c.a
+// holds ah and `al` the remainder when kSplit; beyond |Dn| >= 2^24 (n > 8192) the two fma round once each, which the
+// error budget above allows for.
+__device__ __forceinline__ void f32_split_a(float a, float &ah, float &al)
+{
+    ah = (float)((uint32_t)a & ~15u);
+    al = a - ah;
+}
+
+template <int W, typename Cell, bool kSmallN = false, bool kSplit = false>
 __device__ __forceinline__ void ld_multi_f32(const float (&cnt)[W], const F32Const &k, const F32Row (&r)[W],
-                                             const F32Col (&c)[W], Cell (&out)[W], float &wmax, float &ymin)
+                                             const F32Col (&c)[W], Cell (&out)[W], float &wmax, float &ymin,
+                                             const float *al = nullptr)
 {
     float p[W], e[W], dn[W], t[W], yr[W], x[W], y[W], yd[W], ar[W], ad[W], kr[W], kd[W], fr_[W], fd[W];
     __builtin_amdgcn_sched_barrier(0);
     LDX_STAGE(p[t_] = r[t_].a * c[t_].a)
     if constexpr (kSmallN) {
         LDX_STAGE(dn[t_] = __builtin_fmaf(cnt[t_], k.n, -p[t_]))                    // Dn, exact: p is
+    } else if constexpr (kSplit) {
+        LDX_STAGE(dn[t_] = __builtin_fmaf(cnt[t_], k.n, -p[t_]))                    // Dn + a1 al, exact (p = a1 ah is)
+        LDX_STAGE(dn[t_] = __builtin_fmaf(-r[t_].a, al[t_], dn[t_]))                // Dn, exact below 2^24
     } else {
         LDX_STAGE(e[t_] = __builtin_fmaf(r[t_].a, c[t_].a, -p[t_]); dn[t_] = __builtin_fmaf(cnt[t_], k.n, -p[t_]))
         LDX_STAGE(dn[t_] = dn[t_] - e[t_])                                          // Dn, exact below 2^24
@@ -475,7 +492,7 @@ __device__ __forceinline__ void ld_multi_f32(const float (&cnt)[W], const F32Con
     LDX_STAGE(kd[t_] = ad[t_] - kMagic; fr_[t_] = yr[t_] - kr[t_])
     LDX_STAGE(fd[t_] = yd[t_] - kd[t_]; fr_[t_] = __builtin_fmaf(yr[t_], kEtaR, __builtin_fabsf(fr_[t_])))
     LDX_STAGE(fd[t_] = __builtin_fmaf(yd[t_], kEtaD, __builtin_fabsf(fd[t_])))
-    LDX_STAGE(wmax = __builtin_fmaxf(wmax, __builtin_fmaxf(fr_[t_], fd[t_])); ymin = __builtin_fminf(ymin, yd[t_]))
+    LDX_STAGE(wmax = __builtin_fmaxf(__builtin_fmaxf(wmax, fr_[t_]), fd[t_]); ymin = __builtin_fminf(ymin, yd[t_]))   // one v_max3 per pair
     if constexpr (std::is_same<Cell, ldx_k16>::value) {   // the low mantissa bits of 2^23 + k are k: one byte permute per cell
         LDX_STAGE(out[t_] = __builtin_bit_cast(ldx_k16, __builtin_amdgcn_perm(__float_as_uint(ad[t_]), __float_as_uint(ar[t_]),
                                                                              0x05040100u)))

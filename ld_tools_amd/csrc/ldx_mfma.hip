@@ -906,6 +906,11 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                     const v4f v = *reinterpret_cast<const v4f *>(ct + 32u * tt * 4u);
                     cols[tt] = F32Col{v.x, v.y, v.z, v.w};
                 }
+                float cal[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // n > 4096: the columns' counts split (ldx_common.h, f32_split_a): a = ah + al
+                if (!f32_small_n((double)fc32.n)) {
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) f32_split_a(cols[tt].a, cols[tt].a, cal[tt]);
+                }
                 // the sixteen steps, in two instantiations: n <= 4096 needs no error term for the product a1 a2 (ldx_common.h)
                 auto steps = [&](auto small_c) -> bool {
 #pragma unroll 1
@@ -931,7 +936,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                             c4[tt] = acc[g][tt][e];
                             r4[tt] = rows[g];
                         }
-                        ld_multi_f32<4, Cell, decltype(small_c)::value>(c4, fc32, r4, cols, o4, wmax, ymin);
+                        ld_multi_f32<4, Cell, decltype(small_c)::value, !decltype(small_c)::value>(c4, fc32, r4, cols, o4, wmax, ymin, cal);
 #pragma unroll
                         for (int tt = 0; tt < 4; ++tt) cell[g * 4 + tt] = o4[tt];
                     }

@@ -206,7 +206,12 @@ __device__ inline Cell all_tiers(double n, double rn, uint32_t c11, double fa1, 
             Cell h_[1];
             float wmax = 0.0f, ymin = 1.0f;
             if (f32_small_n(n)) ld_multi_f32<1, Cell, true>(cnt_, f32k, r32, c32, h_, wmax, ymin);   // the variant the kernel picks for this n
-            else ld_multi_f32<1, Cell, false>(cnt_, f32k, r32, c32, h_, wmax, ymin);
+            else {   // the split form the kernel uses for n > 4096
+                F32Col cs[1] = {c32[0]};
+                float al_[1];
+                f32_split_a(cs[0].a, cs[0].a, al_[0]);
+                ld_multi_f32<1, Cell, false, true>(cnt_, f32k, r32, cs, h_, wmax, ymin, al_);
+            }
             f32_sure = (wmax < f32k.tol) & (ymin > 0.0f);
             if (f32_sure) same = same && same_cell(h_[0], res);
         }
