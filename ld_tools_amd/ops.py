@@ -405,7 +405,7 @@ def ld_area(panel: PackedPanel, positions, queries: Optional[Sequence[int]] = No
             try:                                    # capture the launches once; a failure leaves the eager path
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):   # other threads (the shells' table workers) keep allocating
                     _area_launch(panel, pos, q, nq, flank, measure, thres, plan)
                 plan.graph = g
             except Exception:                       # noqa: BLE001
