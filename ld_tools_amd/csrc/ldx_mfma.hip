@@ -421,16 +421,33 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
         }
         const bool short_pass = ticket >= n_norm;                              // block-uniform
         const uint32_t hsel = short_pass ? (ticket - n_norm) & 1u : 0u;        // which 32-row half
-        const uint32_t p = p_begin + (short_pass ? n_norm + ((ticket - n_norm) >> 1) : ticket);
+        // The triangle's tickets walk the j-tiles from the LAST to the first (inside a tile forwards): the last tiles are the
+        // small ones -- one or two passes each, all on the diagonal, i.e. through the slow general epilogue -- and a launch
+        // that ends with them ends with its longest items; reversed, it ends with the uniform passes of tile 0, which the
+        // half-height tickets then split (round 4; the band keeps its position order for the L2).
+        const uint32_t seq = short_pass ? n_norm + ((ticket - n_norm) >> 1) : ticket;   // position in the ticket order
+        uint32_t p = p_begin + seq;
         auto pbase = [&](uint32_t tile) { return kArea ? aa.pass_base[tile] : mfma_pass_base(tile, n_slabs); };
-        uint32_t t;
-        {
-            uint32_t lo = 0, hi = n_slabs;   // largest t with pass_base(t) <= p
+        auto tile_of_pass = [&](uint32_t pp) {
+            uint32_t lo = 0, hi = n_slabs;   // largest t with pass_base(t) <= pp
             while (hi - lo > 1) {
                 const uint32_t mid = (lo + hi) / 2;
-                if (pbase(mid) <= p) lo = mid; else hi = mid;
+                if (pbase(mid) <= pp) lo = mid; else hi = mid;
             }
-            t = lo;
+            return lo;
+        };
+        uint32_t t;
+#ifndef LDX_AB_FORWARD_TILES
+        if constexpr (!kArea) {
+            const uint32_t mirrored = p_end - 1u - seq;   // the pass at the same distance from the end
+            t = tile_of_pass(mirrored);
+            const uint32_t lo_t = pbase(t) > p_begin ? pbase(t) : p_begin;
+            const uint32_t hi_t = (t + 1u < n_slabs && pbase(t + 1u) < p_end) ? pbase(t + 1u) : p_end;
+            p = lo_t + (hi_t - 1u - mirrored);
+        } else
+#endif
+        {
+            t = tile_of_pass(p);
         }
         const bool new_tile = t != t_prev;
         t_prev = t;
