@@ -207,6 +207,7 @@ struct AreaArgs {
     const uint32_t *pass_base;     // [T + 1] prefix sum of passes per j-tile (pass_base[T] = all passes)
     const uint32_t *g_begin;       // [T] first 64-row group of tile t that can hold a hit (2t unless the queries end before the tile)
     const uint32_t *g_end;         // [T] one past the last such group
+    const uint32_t *order;         // [passes] ticket -> pass (area_band_plan_kernel: per XCD range the tiles' FIRST passes first), or null
     ldx_hit *hits;
     uint32_t *counts;              // [n_snps] or null: hits per query row, counted as they are appended (ldx_area_scan_dev)
     unsigned long long *n_hits;
@@ -224,10 +225,11 @@ constexpr uint32_t kQueueCap = 128;   // fp32 tier: lane-steps a wave can park f
 #endif
 // dynamic LDS of the kernel: the two j-tile image buffers, the fp64 operand tables, tickets, and for the FP4 triangle
 // kernel the fp32 tables and the four queues
-constexpr size_t mfma_lds_bytes(uint32_t stat_rows, bool f32_tier)
+constexpr size_t mfma_lds_bytes(uint32_t stat_rows, bool f32_tier, bool band_f32 = false)
 {
     return 2u * kBBuf + (kSlab + kMfmaWaves * stat_rows) * kStat * sizeof(double) + 32u +
-           (f32_tier ? (kSlab + kMfmaWaves * kRows64) * 16u + kMfmaWaves * kQueueCap * 36u + kMfmaWaves * 64u * 4u : 0u);
+           (f32_tier ? (kSlab + kMfmaWaves * kRows64) * 16u + kMfmaWaves * kQueueCap * 36u + kMfmaWaves * 64u * 4u : 0u) +
+           (band_f32 ? (kSlab + kMfmaWaves * kRows64) * 16u : 0u);   // the band's float32 screening tables (same place as the tier's)
 }
 
 // tuning build -DLDX_MM1: every ticket half-height (32-row accumulator tiles only), three workgroups per CU
@@ -361,6 +363,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
     uint32_t *cols_odd = tickets + 2;   // [2]: per wave of the column stagers, != 0 if one of its columns is not "ordinary"
     // fp32 tier (ldx_common.h, ld_multi_f32): its per-SNP tables and each wave's queue of lane-steps for the fp64 tier
     constexpr bool kF32Tier = kFp4 && !kRaw && !kN11 && !kArea;
+    constexpr bool kBandF32 = kFp4 && kArea;   // the band screens its steps in float32 first (area_epilogue)
     float *ctab32 = reinterpret_cast<float *>(tickets + 8);                 // [128][4]: F32Col
     float *rtab32 = ctab32 + kSlab * 4u + wave * (kRows64 * 4u);            // [64][4]: F32Row, private to the wave
     uint32_t *qid = reinterpret_cast<uint32_t *>(ctab32 + kSlab * 4u + kMfmaWaves * kRows64 * 4u) + wave * kQueueCap;   // [kQueueCap]
@@ -379,12 +382,12 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
     const uint32_t my_xcd = kArea ? (__builtin_amdgcn_s_getreg(63508) & 7u) : 0u;   // XCC_ID
     auto draw = [&]() -> uint32_t {
         if constexpr (kArea) {
-            for (uint32_t k = 0; k < 8u; ++k) {
+            for (uint32_t k = 0; k < 8u; ++k) {   // the ranges are cut at TILES (eighths of the tile list): the plan's order is per range
                 const uint32_t x = (my_xcd + k) & 7u;
-                const uint32_t lo = (uint32_t)((uint64_t)n_tickets * x / 8u), hi = (uint32_t)((uint64_t)n_tickets * (x + 1u) / 8u);
+                const uint32_t lo = aa.pass_base[(uint32_t)((uint64_t)n_slabs * x / 8u)], hi = aa.pass_base[(uint32_t)((uint64_t)n_slabs * (x + 1u) / 8u)];
                 if (lo == hi) continue;
                 const uint32_t got = atomicAdd(&sched[2u + 32u * x], 1u);
-                if (got < hi - lo) return lo + got;
+                if (got < hi - lo) return aa.order ? aa.order[lo + got] : lo + got;
             }
             return n_tickets;   // every range is exhausted
         } else {
@@ -618,6 +621,11 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                         const F32Col c32 = f32_col(c.a, c.ra, c.rr, !odd);
                         *reinterpret_cast<v4f *>(ctab32 + tid * 4u) = v4f{c32.a, c32.ra, c32.rr, c32.s};
                     }
+                    if constexpr (kBandF32) {   // the band's float32 screen (area_epilogue): a = ah + al, 10 / sqrt(a r) (inf for a count of 0)
+                        float ah, al;
+                        f32_split_a((float)c.a, ah, al);
+                        *reinterpret_cast<v4f *>(ctab32 + tid * 4u) = v4f{ah, al, (float)(10.0 * __builtin_sqrt(c.rq)), 0.0f};
+                    }
                 }
                 const uint32_t i = row0 + (MM == 1 ? l32 : lane);   // a half-height unit has 32 rows: stay inside the padded vectors
                 const FastRow r = fast_row(fa[i], fr[i], n);
@@ -633,6 +641,9 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                     const F32Row r32 = f32_row(r.a_s * 1e-4, r.ra, r.rr, row_ordinary);   // 1e4 a / 1e4: exact (a < 2^32)
                     *reinterpret_cast<v4f *>(rtab32 + lane * 4u) = v4f{r32.a, r32.ra_s, r32.rr_s, r32.s};
                 }
+                if constexpr (kBandF32)
+                    *reinterpret_cast<v4f *>(rtab32 + lane * 4u) =
+                        v4f{(float)(r.a_s * 1e-4), (float)(10.0 * __builtin_sqrt(r.ra * r.rr)), 0.0f, 0.0f};
                 if (kArea) dst[2] = i < n_snps ? d2{(double)aa.pos[i], (double)(aa.is_query ? aa.is_query[i] : (uint8_t)1)} : d2{0.0, 0.0};
             }
             if (ktok && tid == 0)   // one workgroup per CU in its K loop at a time (see g_sched)
@@ -1122,11 +1133,53 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                     }
                     slot += cnt;
                 };
+                // Float32 screen of a whole step (r^2 thresholds): hits are rare, and the fp64 prefilter below still costs every
+                // (step, column tile) three 16-byte LDS reads per lane and ~7 double-rate instructions per pair.  With this lane's
+                // four columns held in registers as {ah, al, 10 / sqrt(a r)} and the step's two rows read as {a, 10 / sqrt(a r)},
+                // y = ((Dn s1) s2)^2 = 10^4 r^2 costs 7 single-rate instructions per pair (Dn exact through the split column
+                // count, f32_split_a; relative error of y ~1e-6, i.e. < 0.01 of the threshold's units); a step in which no
+                // lane comes within 2.5 units of the threshold -- whatever the pair's validity or window -- is skipped
+                // before any of its fp64 operands are read.  The fp64 prefilter and the full epilogue decide everything else, so
+                // hits are unchanged.  (A count of 0 gives inf or NaN here as there: inf passes, NaN does not.)
+                const bool screen = kBandF32 && prefilter && aa.measure == LDX_MEASURE_RSQ;
+                float sc_ah[4], sc_al[4], sc_s[4];
+                const float sc_n = aa.f32.n, sc_k = (float)(kcand - 0.5);
+                if constexpr (kBandF32) {
+                    if (screen) {
+#pragma unroll
+                        for (int tt = 0; tt < 4; ++tt) {
+                            const v4f v = *reinterpret_cast<const v4f *>(ctab32 + (32u * tt + l32) * 4u);
+                            sc_ah[tt] = v.x;
+                            sc_al[tt] = v.y;
+                            sc_s[tt] = v.z;
+                        }
+                    }
+                }
 #pragma unroll 1
                 for (int e = 0; e < 16; ++e) {
                     uint32_t ri[2];
                     FastRow frx[2];
                     double pi[2], qi[2];
+                    if constexpr (kBandF32) {
+                        if (screen) {
+                            float ymax = 0.0f;
+#pragma unroll
+                            for (int m = 0; m < 2; ++m) {
+                                typedef float v2f __attribute__((ext_vector_type(2)));
+                                const v2f rv = *reinterpret_cast<const v2f *>(rtab32 + (32u * m + (e & 3) + 8u * (e >> 2) + 4u * half) * 4u);
+                                float dn[4], t[4];
+#pragma unroll
+                                for (int tt = 0; tt < 4; ++tt) dn[tt] = __builtin_fmaf(acc[m][tt][e], sc_n, -(rv.x * sc_ah[tt]));
+#pragma unroll
+                                for (int tt = 0; tt < 4; ++tt) dn[tt] = __builtin_fmaf(-rv.x, sc_al[tt], dn[tt]);
+#pragma unroll
+                                for (int tt = 0; tt < 4; ++tt) t[tt] = (dn[tt] * rv.y) * sc_s[tt];
+#pragma unroll
+                                for (int tt = 0; tt < 4; ++tt) ymax = __builtin_fmaxf(ymax, t[tt] * t[tt]);
+                            }
+                            if (!__any(ymax >= sc_k)) continue;   // wave-uniform
+                        }
+                    }
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
                         ri[m] = 32u * m + (e & 3) + 8u * (e >> 2) + 4u * half;
@@ -1208,6 +1261,15 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 area_epilogue();
                 if (tid == 0) tickets[parity] = next_ticket;
                 if (!(ablate & 16)) __builtin_amdgcn_s_setprio(0);
+#ifdef LDX_TUNING
+                LDX_STAMP(3);
+                ++npass;
+                if (my_stamps && lane == 0) {
+                    my_stamps[3] = npass;
+                    my_stamps[4] = __builtin_amdgcn_s_memrealtime();
+                    my_stamps[5] = __builtin_amdgcn_s_memtime();
+                }
+#endif
                 return;
             }
             // `inside`: the unit lies wholly below the diagonal, inside the panel and inside [u_begin, u_end) (no validity
@@ -1489,12 +1551,13 @@ __global__ void __launch_bounds__(1024) area_band_plan_kernel(const int64_t *__r
                                                               int64_t flank, const uint32_t *__restrict__ queries,
                                                               uint32_t n_query, uint32_t *__restrict__ g_begin,
                                                               uint32_t *__restrict__ g_end, uint32_t *__restrict__ pass_base,
-                                                              unsigned long long *__restrict__ n_hits)
+                                                              unsigned long long *__restrict__ n_hits, uint32_t *__restrict__ order,
+                                                              uint32_t *__restrict__ first_base)
 {
     const uint32_t qmin = queries[0], qmax = queries[n_query - 1u];
-    __shared__ uint32_t carry;
-    __shared__ uint32_t wsum[16];
-    if (threadIdx.x == 0) { carry = 0; pass_base[0] = 0; *n_hits = 0ull; }   // (the slot counter of the scan that follows: no memset node)
+    __shared__ unsigned long long carry;
+    __shared__ unsigned long long wsum[16];
+    if (threadIdx.x == 0) { carry = 0; pass_base[0] = 0; first_base[0] = 0; *n_hits = 0ull; }   // (the slot counter of the scan that follows: no memset node)
     block_sync();
     for (uint32_t t0 = 0; t0 < T; t0 += 1024u) {
         const uint32_t t = t0 + threadIdx.x;
@@ -1516,26 +1579,62 @@ __global__ void __launch_bounds__(1024) area_band_plan_kernel(const int64_t *__r
             g_end[t] = ge;
             cnt = (ge - gb + kMfmaWaves - 1u) / kMfmaWaves;
         }
-        uint32_t x = cnt;
+        // two prefix sums in one 64-bit scan: passes (low word) and tiles that have at least one pass (high word)
+        unsigned long long x = (unsigned long long)cnt | ((unsigned long long)(cnt != 0u) << 32);
         const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(x, off); if (lane >= (uint32_t)off) x += y; }
+        for (int off = 1; off < 64; off <<= 1) { const unsigned long long y = __shfl_up(x, off); if (lane >= (uint32_t)off) x += y; }
         if (lane == 63) wsum[wv] = x;
         block_sync();
-        uint32_t pre = 0;
+        unsigned long long pre = 0;
         for (uint32_t k = 0; k < wv; ++k) pre += wsum[k];
-        const uint32_t incl = carry + pre + x;
-        if (t < T) pass_base[t + 1u] = incl;
+        const unsigned long long incl = carry + pre + x;
+        if (t < T) {
+            pass_base[t + 1u] = (uint32_t)incl;
+            first_base[t + 1u] = (uint32_t)(incl >> 32);
+        }
         block_sync();
         if (threadIdx.x == 1023) carry = incl;
         block_sync();
     }
+    // Ticket order (ticket -> pass).  The kernel hands the passes out per XCD: eight contiguous ranges of TILES, walked in
+    // position order for the L2s.  A tile's FIRST pass holds its diagonal units -- where the hits are, i.e. where the full
+    // fp64 epilogue runs (round 4 stamps: epilogue 97k cycles against 11k for the other passes) -- and in plain tile order a
+    // range ended with such passes while the rest of the chip idled (wave slots 76 % busy).  So inside each range all first
+    // passes come first, in tile order, then the other passes in tile order: the launch ends with short items.
+    if (!order) return;   // (a panel whose full triangle has more than kOrderCap passes: plain tile order)
+    __threadfence_block();
+    block_sync();
+    for (uint32_t t = threadIdx.x; t < T; t += 1024u) {
+        uint32_t a = 0, b = T;
+        for (uint32_t xr = 0; xr < 8u; ++xr) {
+            const uint32_t lo = (uint32_t)((uint64_t)T * xr / 8u), hi = (uint32_t)((uint64_t)T * (xr + 1u) / 8u);
+            if (t >= lo && t < hi) { a = lo; b = hi; }
+        }
+        const uint32_t pb = pass_base[t], cnt = pass_base[t + 1u] - pb;
+        if (!cnt) continue;
+        const uint32_t r0 = pass_base[a], nfirst = first_base[b] - first_base[a], kf = first_base[t] - first_base[a];
+        order[r0 + kf] = pb;
+        const uint32_t lt = (pb - r0) - kf;   // passes other than first ones before this tile, inside the range
+        for (uint32_t i = 1; i < cnt; ++i) order[r0 + nfirst + lt + (i - 1u)] = pb + i;
+    }
+}
+
+// room for the band's ticket order: one word per pass of the FULL triangle (what a band can need at most), for panels up
+// to ~512 000 SNPs; beyond that the band keeps plain tile order
+constexpr size_t kOrderCap = 4u << 20;
+static size_t area_order_entries(uint32_t n_snps)
+{
+    const uint32_t T = n_slabs(n_snps);
+    const size_t worst = mfma_pass_base(T, T);
+    return worst <= kOrderCap ? worst : 0u;
 }
 
 size_t area_mfma_workspace_bytes(uint32_t n_snps)
 {
     const size_t T = n_slabs(n_snps);
-    return ((size_t)n_snps + 255u) / 256u * 256u + ((T + 1u) * 4u + 255u) / 256u * 256u + 2u * ((T * 4u + 255u) / 256u * 256u);
+    return ((size_t)n_snps + 255u) / 256u * 256u + 2u * (((T + 1u) * 4u + 255u) / 256u * 256u) + 2u * ((T * 4u + 255u) / 256u * 256u) +
+           (area_order_entries(n_snps) * 4u + 255u) / 256u * 256u;
 }
 
 int area_mfma(const void *alt, const double *fa, const double *fr, const double *q, uint32_t n_snps, uint32_t n_hap,
@@ -1551,6 +1650,10 @@ int area_mfma(const void *alt, const double *fa, const double *fr, const double 
     uint32_t *g_end = (uint32_t *)w;
     w += ((size_t)T * 4u + 255u) / 256u * 256u;
     uint32_t *g_begin = (uint32_t *)w;
+    w += ((size_t)T * 4u + 255u) / 256u * 256u;
+    uint32_t *first_base = (uint32_t *)w;   // [T + 1] tiles with at least one pass before tile t
+    w += (((size_t)T + 1u) * 4u + 255u) / 256u * 256u;
+    uint32_t *order = area_order_entries(n_snps) ? (uint32_t *)w : nullptr;
     if (n_query == n_snps) {   // ascending distinct rows: every SNP is a query -- no mask at all
         is_query = nullptr;
     } else {
@@ -1559,18 +1662,20 @@ int area_mfma(const void *alt, const double *fa, const double *fr, const double 
         LDX_HIP(hipGetLastError());
     }
     area_band_plan_kernel<<<1, 1024, 0, s>>>(positions, n_snps, T, flank, queries, n_query, g_begin, g_end, pass_base,
-                                             (unsigned long long *)n_hits);
+                                             (unsigned long long *)n_hits, order, first_base);
     LDX_HIP(hipGetLastError());
-    const size_t lds = mfma_lds_bytes(kRows64, false);
+    const size_t lds = mfma_lds_bytes(kRows64, false, fp4);
     const int cus = device_cus();
     uint32_t *sched = nullptr;
     AreaArgs aa{};
     if (int rc = acquire_sched(s, &sched, &aa.launch_seq)) return rc;
+    aa.f32 = f32_const((double)n_hap);
     aa.pos = positions;
     aa.is_query = is_query;
     aa.pass_base = pass_base;
     aa.g_begin = g_begin;
     aa.g_end = g_end;
+    aa.order = order;
     aa.hits = hits;
     aa.counts = query_counts;
     aa.n_hits = (unsigned long long *)n_hits;
@@ -1579,15 +1684,39 @@ int area_mfma(const void *alt, const double *fa, const double *fr, const double 
     aa.k_thres = thres_to_k(thres);
     aa.measure = measure;
     const uint64_t units = ldx_triangle_units(n_snps) / 8u;   // 64-row units of the full triangle
+    unsigned long long *stamps = nullptr;
+#ifdef LDX_TUNING   // in-kernel stamps of the band (env LDX_STAMPS=file), as in launch_mfma
+    const char *stamp_file = getenv("LDX_STAMPS");
+    const size_t stamp_words = (size_t)cus * 2u * kMfmaWaves * kStampStride;
+    if (stamp_file) {
+        LDX_HIP(hipMalloc(&stamps, stamp_words * 8));
+        LDX_HIP(hipMemsetAsync(stamps, 0, stamp_words * 8, s));
+    }
+#endif
     if (fp4)
         triangle_mfma_kernel<false, false, true, true><<<(uint32_t)cus * 2u, kMfmaThreads, lds, s>>>(
             (const uint4 *)alt, fa, fr, q, n_snps, T, nch, (double)n_hap, 1.0 / (double)n_hap, 0, units * 8u,
-            (ldx_ld32 *)nullptr, nullptr, nullptr, 0u, 0u, 0u, sched, 0, nullptr, aa);
+            (ldx_ld32 *)nullptr, nullptr, nullptr, 0u, 0u, 0u, sched, 0, stamps, aa);
     else
         triangle_mfma_kernel<false, false, true, false><<<(uint32_t)cus * 2u, kMfmaThreads, lds, s>>>(
             (const uint4 *)alt, fa, fr, q, n_snps, T, nch, (double)n_hap, 1.0 / (double)n_hap, 0, units * 8u,
             (ldx_ld32 *)nullptr, nullptr, nullptr, 0u, 0u, 0u, sched, 0, nullptr, aa);
     LDX_HIP(hipGetLastError());
+#ifdef LDX_TUNING
+    if (stamps) {   // tuning only: synchronous; the file holds the stamps of the LAST launch
+        unsigned long long *h = (unsigned long long *)malloc(stamp_words * 8);
+        LDX_HIP(hipStreamSynchronize(s));
+        LDX_HIP(hipMemcpy(h, stamps, stamp_words * 8, hipMemcpyDeviceToHost));
+        if (FILE *f = fopen(stamp_file, "wb")) {
+            const unsigned long long hdr[4] = {(unsigned long long)cus * 2u, (unsigned long long)kMfmaWaves, kStampStride, kStampPasses};
+            fwrite(hdr, 8, 4, f);
+            fwrite(h, 8, stamp_words, f);
+            fclose(f);
+        }
+        free(h);
+        LDX_HIP(hipFree(stamps));
+    }
+#endif
     return LDX_OK;
 }
 

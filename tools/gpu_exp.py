@@ -81,6 +81,26 @@ def main():
         dt = (time.perf_counter() - t0) / 5
         out.update(first_call_s=first, s=dt, ordered_pairs=hits.n_pairs, hits=len(hits),
                    ordered_pairs_per_s=hits.n_pairs / dt)
+    elif what == "area2":   # configs[2] as bench.py times it: the product call (one HIP graph) and the scan alone (HIP events)
+        n, h = 100000, 5008
+        p = PackedPanel.from_codes(synth.synth_codes_device(n, h))
+        pos = torch.as_tensor(synth.synth_positions(n, step=500)).to(p.device)
+        for _ in range(3):
+            hits = ld_area(p, pos, None, 500000, "r_square", 0.8, check_positions=False)
+        torch.cuda.synchronize()
+        reps, ev, scan = 20, [], []
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            hits = ld_area(p, pos, None, 500000, "r_square", 0.8, check_positions=False)
+            torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / reps
+        for _ in range(reps):
+            ld_area(p, pos, None, 500000, "r_square", 0.8, check_positions=False, events=ev)
+            torch.cuda.synchronize()
+            scan.append(ev[0].elapsed_time(ev[1]))
+        scan.sort()
+        out.update(end_to_end_ms=wall * 1e3, scan_ms_median=scan[len(scan) // 2], scan_ms_min=scan[0], hits=len(hits),
+                   ordered_pairs=hits.n_pairs)
     elif what == "tri100k":
         n, h = 100000, 5008
         p = PackedPanel.from_codes(synth.synth_codes_device(n, h))
