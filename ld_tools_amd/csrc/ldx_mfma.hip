@@ -218,6 +218,7 @@ struct AreaArgs {
     uint32_t launch_seq;           // this launch's number on its ticket-counter slot (acquire_sched): written back when it ends
 };
 constexpr uint32_t kHitBatch = 256;   // hit slots a wave reserves per atomic (as in ldx_area.hip)
+constexpr uint32_t kAreaQueue = 256;  // band: candidate pairs a wave collects before it evaluates them, one per lane
 #ifdef LDX_MM1   // tuning build with three workgroups per CU: 53 KB of LDS each
 constexpr uint32_t kQueueCap = 32;
 #else
@@ -229,7 +230,8 @@ constexpr size_t mfma_lds_bytes(uint32_t stat_rows, bool f32_tier, bool band_f32
 {
     return 2u * kBBuf + (kSlab + kMfmaWaves * stat_rows) * kStat * sizeof(double) + 32u +
            (f32_tier ? (kSlab + kMfmaWaves * kRows64) * 16u + kMfmaWaves * kQueueCap * 36u + kMfmaWaves * 64u * 4u : 0u) +
-           (band_f32 ? (kSlab + kMfmaWaves * kRows64) * 16u : 0u);   // the band's float32 screening tables (same place as the tier's)
+           (band_f32 ? (kSlab + kMfmaWaves * kRows64) * 16u + kMfmaWaves * kAreaQueue * 8u : 0u);   // the band's float32 screening
+                                                                     // tables (same place as the tier's) and candidate queues
 }
 
 // tuning build -DLDX_MM1: every ticket half-height (32-row accumulator tiles only), three workgroups per CU
@@ -371,6 +373,8 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                                             kMfmaWaves * kQueueCap) + wave * (kQueueCap * 8u);   // [kQueueCap][8] counts
     uint32_t *ulist = reinterpret_cast<uint32_t *>(ctab32 + kSlab * 4u + kMfmaWaves * kRows64 * 4u) + kMfmaWaves * kQueueCap * 9u +
                       wave * 64u;   // [64]: parked pairs deferred to the mirror batch (entry << 3 | pair)
+    uint32_t *aq_id = reinterpret_cast<uint32_t *>(ctab32 + kSlab * 4u + kMfmaWaves * kRows64 * 4u) + wave * kAreaQueue;   // band: [kAreaQueue]
+    uint32_t *aq_cnt = reinterpret_cast<uint32_t *>(ctab32 + kSlab * 4u + kMfmaWaves * kRows64 * 4u) + kMfmaWaves * kAreaQueue + wave * kAreaQueue;
     const F32Const fc32 = aa.f32;   // computed on the host (f32_const): kernel arguments live in scalar registers
     // The band (ld_area) hands its passes out PER XCD: the pass list -- j-tile-major, i.e. sorted by position -- is cut into
     // eight contiguous ranges, one per XCD, each with its own counter (sched[2 + 32 x]: the K-loop-token words, which the
@@ -1155,11 +1159,67 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                         }
                     }
                 }
+                // Candidates are COLLECTED, not evaluated where they are found: a pair that the (fp64) prefilter cannot rule out --
+                // valid cells only: the upper triangle of a diagonal unit mirrors real hits -- goes into the wave's LDS queue
+                // (step, row tile, column tile, lane + the accumulator word), and the full epilogue runs over the queue with ONE
+                // PAIR PER LANE.  Hits cluster near the diagonal: evaluated in place, every step of a tile's first pass ran the
+                // full fp64 epilogue for two or three of its column tiles, each time for 128 pairs of which a handful mattered
+                // (round 4 stamps: 97k cycles per such pass against 11k for the others, 40 % of the kernel's work).
+                uint32_t aqn = 0;   // queued candidates (wave-uniform)
+                auto drain = [&]() {
+                    if (!aqn) return;
+                    LDX_COUNT(0, 1);     // tuning builds: drains, candidates evaluated
+                    LDX_COUNT(1, aqn);
+                    __builtin_amdgcn_s_waitcnt(0xC07F);   // this wave's queue writes have landed
+                    __builtin_amdgcn_wave_barrier();
+                    for (uint32_t q0 = 0; q0 < aqn; q0 += 64u) {   // wave-uniform
+                        const uint32_t ent = q0 + lane;
+                        const bool live = ent < aqn;
+                        const uint32_t id = live ? aq_id[ent] : 0u;
+                        const uint32_t e2 = id >> 9, m2 = (id >> 8) & 1u, tt2 = (id >> 6) & 3u, l2 = id & 63u;
+                        const uint32_t ri2 = 32u * m2 + (e2 & 3u) + 8u * (e2 >> 2) + 4u * (l2 >> 5), cl = 32u * tt2 + (l2 & 31u);
+                        const uint32_t i = row0 + ri2, j = t * kSlab + cl;
+                        accel_t a1[1] = {__builtin_bit_cast(accel_t, live ? aq_cnt[ent] : 0u)};
+                        const d2 *rs = reinterpret_cast<const d2 *>(rstat + ri2 * kStat);
+                        const d2 r01 = rs[0], r23 = rs[1], r45 = rs[2];
+                        const FastRow fr1[1] = {FastRow{r01.x, r01.y, r23.x, r23.y}};
+                        const double pi = r45.x, qi = r45.y;
+                        const d2 *cs = reinterpret_cast<const d2 *>(cstat + cl * kStat);
+                        const d2 c01 = cs[0], c23 = cs[1], c45 = cs[2];
+                        const FastCol fc1[1] = {FastCol{c01.x, c01.y, c23.x, c23.y}};
+                        const double pj = c45.x, qj = c45.y;
+                        ldx_ld32 r1[1];
+                        bool s1[1];
+                        ld_multi_fast2<1, false, ldx_ld32>(a1, fk, fr1, fc1, r1, s1);
+                        const bool valid = live && (i > j) && (i < n_snps);
+                        double low = pi - aa.flank;
+                        low = low < 0.0 ? 0.0 : low;
+                        const bool in_a = valid && qi != 0.0 && low < pj;                 // A: query i, opposing j
+                        double lowj = pj - aa.flank;
+                        lowj = lowj < 0.0 ? 0.0 : lowj;
+                        const bool in_b = valid && qj != 0.0 && lowj < pi && pi <= pj + aa.flank;   // B: query j, opposing i
+                        ldx_ld32 ra = r1[0], rb = r1[0];
+                        if (__builtin_expect(__any(s1[0] && (in_a || in_b)), 0)) {
+                            if (s1[0] && (in_a || in_b)) {
+                                const double f11 = (double)count_of(a1[0]) / n;
+                                ra = encode_cell<ldx_ld32>(ld_pair_mirror(f11, fa[i], fr[i], q[i], fa[j], fr[j]));
+                                rb = encode_cell<ldx_ld32>(ld_pair_mirror(f11, fa[j], fr[j], q[j], fa[i], fr[i]));
+                            }
+                        }
+                        // rounded value * 10^4 back as an integer (exact for values < 1024; -0.0f = int 0 -> 0; the
+                        // escape NaN of a value >= 1024 counts as +inf: it passes every threshold the band accepts)
+                        const float va = aa.measure == LDX_MEASURE_RSQ ? ra.r_square : ra.d_prime;
+                        const float vb = aa.measure == LDX_MEASURE_RSQ ? rb.r_square : rb.d_prime;
+                        const double ka = va != va ? __builtin_inf() : __builtin_rint((double)va * 1e4);
+                        const double kb = vb != vb ? __builtin_inf() : __builtin_rint((double)vb * 1e4);
+                        append(in_a && ka >= kthr, i, j, ra);                              // ld_area.py:248
+                        append(in_b && kb >= kthr, j, i, rb);
+                    }
+                    aqn = 0;
+                    __builtin_amdgcn_wave_barrier();   // (the next pushes overwrite entries this loop has read)
+                };
 #pragma unroll 1
                 for (int e = 0; e < 16; ++e) {
-                    uint32_t ri[2];
-                    FastRow frx[2];
-                    double pi[2], qi[2];
                     if constexpr (kBandF32) {
                         if (screen) {
                             float ymax = 0.0f;
@@ -1180,79 +1240,70 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                             if (!__any(ymax >= sc_k)) continue;   // wave-uniform
                         }
                     }
+                    uint32_t ri[2];
+                    double ras[2], rqs[2], rra[2], rrr[2];   // the rows' prefilter operands: 1e4 a, 1e-4 / (a r), 1 / a, 1 / r
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
                         ri[m] = 32u * m + (e & 3) + 8u * (e >> 2) + 4u * half;
                         const d2 *rs = reinterpret_cast<const d2 *>(rstat + ri[m] * kStat);
-                        const d2 r01 = rs[0], r23 = rs[1], r45 = rs[2];
-                        frx[m] = FastRow{r01.x, r01.y, r23.x, r23.y};
-                        pi[m] = r45.x;
-                        qi[m] = r45.y;
+                        const d2 r01 = rs[0], r23 = rs[1];
+                        ras[m] = r01.x;
+                        rra[m] = r01.y;
+                        rrr[m] = r23.x;
+                        rqs[m] = r23.y;
                     }
 #pragma unroll
                     for (int tt = 0; tt < 4; ++tt) {
                         const d2 *cs = reinterpret_cast<const d2 *>(cstat + (32u * tt + l32) * kStat);
-                        const d2 c01 = cs[0], c23 = cs[1], c45 = cs[2];
-                        const FastCol fcx[2] = {FastCol{c01.x, c01.y, c23.x, c23.y}, FastCol{c01.x, c01.y, c23.x, c23.y}};
-                        const double pj = c45.x, qj = c45.y;
+                        const d2 c01 = cs[0], c23 = cs[1];
                         const uint32_t j = t * kSlab + 32u * tt + l32;
-                        accel_t a8[2];
-                        ldx_ld32 r2[2];
-                        bool s2[2];
-#pragma unroll
-                        for (int m = 0; m < 2; ++m) a8[m] = acc[m][tt][e];
                         // Prefilter: hits are rare (r^2 >= 0.8: ~6e-4 of the pairs), so first price the thresholded
-                        // measure alone -- 6 VALU for r^2 * 10^4, 15 for D' * 10^4, exact to ~1e-11 -- and run the full
-                        // epilogue only where some lane comes within 2 units of the threshold (the two orders of a pair
+                        // measure alone -- 6 VALU for r^2 * 10^4, 15 for D' * 10^4, exact to ~1e-11 -- and queue only
+                        // the pairs that come within 2 units of the threshold (the two orders of a pair
                         // and the reference's own rounding differ by far less).  A NaN (a count of 0: int-0 results)
-                        // never passes; thresholds <= 2e-4 switch the prefilter off.
-                        if (prefilter) {
-                            bool cand = false;
+                        // never passes; thresholds <= 2e-4 switch the prefilter off: every valid pair is queued.
+                        bool cand[2];
+                        // ONE register-indexed read per accumulator, pinned: hipcc (ROCm 7.2) turned a second `acc[m][tt][e]`
+                        // -- the one stored into the queue below -- into a plain read of element 0 of the tile
+                        // (ds_write_b32 of the tile's first register, no index mode around it; found with tools/gpu_area_diff.py)
+                        accel_t a8[2];
 #pragma unroll
-                            for (int m = 0; m < 2; ++m) {
-                                const double dn4 = __builtin_fma((double)a8[m], fk.nsc, -(frx[m].a_s * fcx[m].a));
-                                double y;
-                                if (aa.measure == LDX_MEASURE_RSQ) {
-                                    y = (dn4 * (frx[m].rq_s * fcx[m].rq)) * dn4;
-                                } else {
-                                    const bool neg = dn4 < 0.0;
-                                    const double x = neg ? fcx[m].ra : fcx[m].rr, yy = neg ? fcx[m].rr : fcx[m].ra;
-                                    y = __builtin_fabs(dn4) * max_raw(frx[m].ra * x, frx[m].rr * yy);
-                                }
-                                cand = cand || (y >= kcand);
-                            }
-                            if (!__any(cand)) continue;   // wave-uniform: nothing near the threshold in these 128 pairs
+                        for (int m = 0; m < 2; ++m) {
+                            a8[m] = acc[m][tt][e];
+                            asm volatile("" : "+v"(a8[m]));
                         }
-                        ld_multi_fast2<2, false, ldx_ld32>(a8, fk, frx, fcx, r2, s2);
 #pragma unroll
                         for (int m = 0; m < 2; ++m) {
                             const uint32_t i = row0 + ri[m];
-                            const bool valid = (i > j) && (i < n_snps);
-                            double low = pi[m] - aa.flank;
-                            low = low < 0.0 ? 0.0 : low;
-                            const bool in_a = valid && qi[m] != 0.0 && low < pj;                 // A: query i, opposing j
-                            double lowj = pj - aa.flank;
-                            lowj = lowj < 0.0 ? 0.0 : lowj;
-                            const bool in_b = valid && qj != 0.0 && lowj < pi[m] && pi[m] <= pj + aa.flank;   // B: query j, opposing i
-                            ldx_ld32 ra = r2[m], rb = r2[m];
-                            if (__builtin_expect(__any(s2[m] && (in_a || in_b)), 0)) {
-                                if (s2[m] && (in_a || in_b)) {
-                                    const double f11 = (double)count_of(a8[m]) / n;
-                                    ra = encode_cell<ldx_ld32>(ld_pair_mirror(f11, fa[i], fr[i], q[i], fa[j], fr[j]));
-                                    rb = encode_cell<ldx_ld32>(ld_pair_mirror(f11, fa[j], fr[j], q[j], fa[i], fr[i]));
+                            cand[m] = (i > j) && (i < n_snps);
+                            if (prefilter) {
+                                const double dn4 = __builtin_fma((double)a8[m], fk.nsc, -(ras[m] * c01.x));
+                                double y;
+                                if (aa.measure == LDX_MEASURE_RSQ) {
+                                    y = (dn4 * (rqs[m] * c23.y)) * dn4;
+                                } else {
+                                    const bool neg = dn4 < 0.0;
+                                    const double x = neg ? c01.y : c23.x, yy = neg ? c23.x : c01.y;
+                                    y = __builtin_fabs(dn4) * max_raw(rra[m] * x, rrr[m] * yy);
                                 }
+                                cand[m] = cand[m] && (y >= kcand);
                             }
-                            // rounded value * 10^4 back as an integer (exact for values < 1024; -0.0f = int 0 -> 0; the
-                            // escape NaN of a value >= 1024 counts as +inf: it passes every threshold the band accepts)
-                            const float va = aa.measure == LDX_MEASURE_RSQ ? ra.r_square : ra.d_prime;
-                            const float vb = aa.measure == LDX_MEASURE_RSQ ? rb.r_square : rb.d_prime;
-                            const double ka = va != va ? __builtin_inf() : __builtin_rint((double)va * 1e4);
-                            const double kb = vb != vb ? __builtin_inf() : __builtin_rint((double)vb * 1e4);
-                            append(in_a && ka >= kthr, i, j, ra);                              // ld_area.py:248
-                            append(in_b && kb >= kthr, j, i, rb);
+                        }
+                        if (!__any(cand[0] || cand[1])) continue;   // wave-uniform: nothing near the threshold in these 128 pairs
+                        if (aqn + 128u > kAreaQueue) drain();       // wave-uniform: room for this column tile's worst case
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) {
+                            const unsigned long long mask = __ballot(cand[m]);
+                            if (cand[m]) {
+                                const uint32_t pos = aqn + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                                aq_id[pos] = ((uint32_t)e << 9) | ((uint32_t)m << 8) | ((uint32_t)tt << 6) | lane;
+                                aq_cnt[pos] = __builtin_bit_cast(uint32_t, a8[m]);
+                            }
+                            aqn += (uint32_t)__builtin_popcountll(mask);
                         }
                     }
                 }
+                drain();
                 hit_slot = slot;
                 hit_slot_end = slot_end;
               }
@@ -1664,7 +1715,19 @@ int area_mfma(const void *alt, const double *fa, const double *fr, const double 
     area_band_plan_kernel<<<1, 1024, 0, s>>>(positions, n_snps, T, flank, queries, n_query, g_begin, g_end, pass_base,
                                              (unsigned long long *)n_hits, order, first_base);
     LDX_HIP(hipGetLastError());
-    const size_t lds = mfma_lds_bytes(kRows64, false, fp4);
+    const size_t lds = mfma_lds_bytes(kRows64, false, true);
+    {   // above 64 KiB the dynamic LDS size needs the opt-in attribute: once per device
+        static std::atomic<uint64_t> opted{0};
+        int dev = 0;
+        LDX_HIP(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 64 || !((opted.load(std::memory_order_relaxed) >> dev) & 1u)) {
+            LDX_HIP(hipFuncSetAttribute((const void *)triangle_mfma_kernel<false, false, true, true>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            LDX_HIP(hipFuncSetAttribute((const void *)triangle_mfma_kernel<false, false, true, false>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            if (dev >= 0 && dev < 64) opted.fetch_or(1ull << dev, std::memory_order_relaxed);
+        }
+    }
     const int cus = device_cus();
     uint32_t *sched = nullptr;
     AreaArgs aa{};
