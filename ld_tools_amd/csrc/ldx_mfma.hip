@@ -1148,6 +1148,8 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 const bool screen = kBandF32 && prefilter && aa.measure == LDX_MEASURE_RSQ;
                 float sc_ah[4], sc_al[4], sc_s[4];
                 const float sc_n = aa.f32.n, sc_k = (float)(kcand - 0.5);
+                const bool sc_diag = row0 < (t + 1u) * kSlab;      // the unit has cells on or above the diagonal (wave-uniform)
+                const uint32_t t_col0 = t * kSlab + l32;            // this lane's column of the tile's first 32
                 if constexpr (kBandF32) {
                     if (screen) {
 #pragma unroll
@@ -1220,13 +1222,15 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 };
 #pragma unroll 1
                 for (int e = 0; e < 16; ++e) {
+                    uint32_t tt_live = 0xFu;   // column tiles of this step that the screen could not rule out (wave-uniform)
                     if constexpr (kBandF32) {
                         if (screen) {
-                            float ymax = 0.0f;
+                            float ymx[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
                             for (int m = 0; m < 2; ++m) {
                                 typedef float v2f __attribute__((ext_vector_type(2)));
-                                const v2f rv = *reinterpret_cast<const v2f *>(rtab32 + (32u * m + (e & 3) + 8u * (e >> 2) + 4u * half) * 4u);
+                                const uint32_t rim = 32u * m + (e & 3) + 8u * (e >> 2) + 4u * half;
+                                const v2f rv = *reinterpret_cast<const v2f *>(rtab32 + rim * 4u);
                                 float dn[4], t[4];
 #pragma unroll
                                 for (int tt = 0; tt < 4; ++tt) dn[tt] = __builtin_fmaf(acc[m][tt][e], sc_n, -(rv.x * sc_ah[tt]));
@@ -1234,10 +1238,17 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                                 for (int tt = 0; tt < 4; ++tt) dn[tt] = __builtin_fmaf(-rv.x, sc_al[tt], dn[tt]);
 #pragma unroll
                                 for (int tt = 0; tt < 4; ++tt) t[tt] = (dn[tt] * rv.y) * sc_s[tt];
+                                if (sc_diag) {   // a unit on the diagonal: cells with row <= column mirror real hits (and i == j is r^2 = 1)
 #pragma unroll
-                                for (int tt = 0; tt < 4; ++tt) ymax = __builtin_fmaxf(ymax, t[tt] * t[tt]);
+                                    for (int tt = 0; tt < 4; ++tt) t[tt] = row0 + rim > t_col0 + 32u * tt ? t[tt] : 0.0f;
+                                }
+#pragma unroll
+                                for (int tt = 0; tt < 4; ++tt) ymx[tt] = __builtin_fmaxf(ymx[tt], t[tt] * t[tt]);
                             }
-                            if (!__any(ymax >= sc_k)) continue;   // wave-uniform
+                            if (!__any(__builtin_fmaxf(__builtin_fmaxf(ymx[0], ymx[1]), __builtin_fmaxf(ymx[2], ymx[3])) >= sc_k)) continue;   // wave-uniform
+                            tt_live = 0u;   // (steps with candidates are rare: four more ballots only here)
+#pragma unroll
+                            for (int tt = 0; tt < 4; ++tt) tt_live |= __any(ymx[tt] >= sc_k) ? 1u << tt : 0u;
                         }
                     }
                     uint32_t ri[2];
@@ -1254,6 +1265,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                     }
 #pragma unroll
                     for (int tt = 0; tt < 4; ++tt) {
+                        if (!((tt_live >> tt) & 1u)) continue;   // wave-uniform
                         const d2 *cs = reinterpret_cast<const d2 *>(cstat + (32u * tt + l32) * kStat);
                         const d2 c01 = cs[0], c23 = cs[1];
                         const uint32_t j = t * kSlab + 32u * tt + l32;
