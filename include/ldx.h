@@ -251,6 +251,13 @@ int ldx_area_finish_ex_dev(ldx_hit *raw, const uint64_t *n_reserved, uint64_t hi
                            ldx_hit *sorted, uint32_t *offsets, uint64_t *summary, void *workspace,
                            size_t workspace_bytes, int counts_ready, void *stream);
 uint32_t *ldx_area_finish_counts(void *finish_workspace);   /* where the finishing step keeps its per-query counts */
+/* The caller's copy of a finished scan in ONE launch: the first n_hits sorted hits split into query rows, opposing rows
+ * (int64 each) and the value pairs (float [n_hits][2]: r_square, d_prime), and -- each optional, NULL to skip -- a copy of
+ * the n_offsets words of the offsets index and of one 32-bit instrumentation word.  (ld_area.py:261-276 reads exactly these
+ * per query; a driver that keeps the scan's buffers for the next table needs its own copy of the result.) */
+int ldx_area_results_dev(const ldx_hit *sorted, uint64_t n_hits, int64_t *query, int64_t *oppos, float *values,
+                         const uint32_t *offsets_src, uint32_t *offsets_dst, uint32_t n_offsets,
+                         const uint32_t *word_src, uint32_t *word_dst, void *stream);
 /* instrumentation: byte offset, inside the workspace of ldx_area_dev, of the uint32 count of passes (4 units of 64 rows
  * x 128 columns) the matrix-pipe band evaluated */
 size_t ldx_area_band_passes_offset(uint32_t n_snps);

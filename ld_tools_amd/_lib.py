@@ -124,6 +124,7 @@ SIGNATURES = {
     "ldx_area_finish_dev": (_int, [_vp, _vp, _u64, _u32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ldx_area_finish_ex_dev": (_int, [_vp, _vp, _u64, _u32, _vp, _vp, _vp, _vp, _sz, _int, _vp]),
     "ldx_area_finish_counts": (_vp, [_vp]),
+    "ldx_area_results_dev": (_int, [_vp, _u64, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp]),
     "ldx_area_finish_workspace_bytes": (_sz, [_u32]),
     "ldx_area_band_passes_offset": (_sz, [_u32]),
     "ldx_set_area_path": (_int, [_int]),

@@ -501,6 +501,46 @@ extern "C" int ldx_area_finish_dev(ldx_hit *raw, const uint64_t *n_reserved, uin
 
 extern "C" uint32_t *ldx_area_finish_counts(void *finish_workspace) { return (uint32_t *)finish_workspace; }
 
+namespace ldx {
+// the caller's copy of a finished scan (ldx_area_results_dev): one grid-stride pass over max(hits, offsets) elements
+__global__ void area_results_kernel(const ldx_hit *__restrict__ sorted, uint64_t n_hits, int64_t *__restrict__ query,
+                                    int64_t *__restrict__ oppos, float2 *__restrict__ values,
+                                    const uint32_t *__restrict__ offsets_src, uint32_t *__restrict__ offsets_dst,
+                                    uint32_t n_offsets, const uint32_t *__restrict__ word_src, uint32_t *__restrict__ word_dst)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x, first = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint64_t k = first; k < n_hits; k += stride) {
+        const ldx_hit h = sorted[k];
+        query[k] = (int64_t)h.query;
+        oppos[k] = (int64_t)h.oppos;
+        values[k] = float2{h.r_square, h.d_prime};
+    }
+    if (offsets_dst)
+        for (uint64_t k = first; k < n_offsets; k += stride) offsets_dst[k] = offsets_src[k];
+    if (word_dst && first == 0) *word_dst = *word_src;
+}
+}  // namespace ldx
+
+extern "C" int ldx_area_results_dev(const ldx_hit *sorted, uint64_t n_hits, int64_t *query, int64_t *oppos, float *values,
+                                    const uint32_t *offsets_src, uint32_t *offsets_dst, uint32_t n_offsets,
+                                    const uint32_t *word_src, uint32_t *word_dst, void *stream)
+{
+    LDX_REQUIRE(n_hits == 0 || (sorted && query && oppos && values), "null pointer");
+    LDX_REQUIRE(!offsets_dst || offsets_src, "offsets_dst without offsets_src");
+    LDX_REQUIRE(!word_dst || word_src, "word_dst without word_src");
+    uint64_t work = n_hits;
+    if (offsets_dst && n_offsets > work) work = n_offsets;
+    if (word_dst && !work) work = 1u;
+    if (!work) return LDX_OK;
+    uint64_t blocks = (work + 255u) / 256u;
+    if (blocks > 4096u) blocks = 4096u;
+    ldx::area_results_kernel<<<(uint32_t)blocks, 256, 0, (hipStream_t)stream>>>(sorted, n_hits, query, oppos,
+                                                                               reinterpret_cast<float2 *>(values), offsets_src,
+                                                                               offsets_dst, n_offsets, word_src, word_dst);
+    LDX_HIP(hipGetLastError());
+    return LDX_OK;
+}
+
 extern "C" int ldx_area_finish_ex_dev(ldx_hit *raw, const uint64_t *n_reserved, uint64_t hit_cap, uint32_t n_snps,
                                       ldx_hit *sorted, uint32_t *offsets, uint64_t *summary, void *workspace,
                                       size_t workspace_bytes, int counts_ready, void *stream)

@@ -422,11 +422,25 @@ def ld_area(panel: PackedPanel, positions, queries: Optional[Sequence[int]] = No
         if key is not None:
             plans.pop(key, None)
         plan = None
-    hits = plan.hits[:total]
-    rows = hits[:, 0:2].to(torch.int64) & 0xFFFFFFFF        # both row columns in one pass (two small kernels, not four)
-    qrow, orow = rows[:, 0], rows[:, 1]
-    ld32 = hits[:, 2:4].contiguous().view(torch.float32)
-    offsets = plan.offsets.clone() if key is not None else plan.offsets     # a kept plan's buffers are overwritten by the next call
+    # the caller's copy of the result -- query / opposing rows as int64, the value pairs, and for a kept plan (whose buffers
+    # the next call overwrites) the offsets index and the band's pass count -- in ONE launch (ldx_area_results_dev; it was
+    # five small torch kernels, ~20 us of a 0.39 ms call)
+    qrow = torch.empty(total, dtype=torch.int64, device=dev)
+    orow = torch.empty(total, dtype=torch.int64, device=dev)
+    ld32 = torch.empty((total, 2), dtype=torch.float32, device=dev)
+    offsets = torch.empty_like(plan.offsets) if key is not None else plan.offsets
+    use_band = get_area_path() != "popcount" and (get_area_path() != "auto" or (nq * 16 >= panel.n_snps and panel.n_snps >= 2))
+    word = None
+    if use_band:
+        off = lib.ldx_area_band_passes_offset(panel.n_snps)
+        word_src = plan.ws[off:off + 4]
+        word = torch.empty(4, dtype=torch.uint8, device=dev) if key is not None else word_src
+    check(lib.ldx_area_results_dev(plan.hits.data_ptr(), total, qrow.data_ptr(), orow.data_ptr(), ld32.data_ptr(),
+                                   plan.offsets.data_ptr(), offsets.data_ptr() if key is not None else None,
+                                   panel.n_snps + 1,
+                                   word_src.data_ptr() if (use_band and key is not None) else None,
+                                   word.data_ptr() if (use_band and key is not None) else None, _stream_ptr()),
+          "ldx_area_results_dev")
 
     def count_pairs() -> int:
         # pairs evaluated = sum over queries of window population (bookkeeping, on device, only when asked for)
@@ -437,9 +451,7 @@ def ld_area(panel: PackedPanel, positions, queries: Optional[Sequence[int]] = No
         return int((hi - lo).sum().item()) - int(self_in.sum().item())
 
     band = None
-    if get_area_path() != "popcount" and (get_area_path() != "auto" or (nq * 16 >= panel.n_snps and panel.n_snps >= 2)):
-        off = lib.ldx_area_band_passes_offset(panel.n_snps)
-        word = plan.ws[off:off + 4].clone() if key is not None else plan.ws[off:off + 4]   # a kept plan is overwritten by the next call
+    if use_band:
         band = lambda: int(word.view(torch.int32).item())    # noqa: E731
     return AreaHits(qrow, orow, ld32, count_pairs, offsets, band)
 
