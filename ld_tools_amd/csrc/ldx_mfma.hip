@@ -723,12 +723,40 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 __builtin_amdgcn_sched_barrier(0);                                                                 \
                 LDX_CSTAMP(5)                                                                                      \
             }
+            // A wave whose unit lies outside the tile's segment (the last pass of a tile: 2 of 4 units every other tile of the
+            // triangle, ~1.5 of 20 in the band's five passes per tile at +-1000 rows) has nothing to count: it keeps up its
+            // share of the j-tile image -- the same loads and the same image writes on the same side of the per-block
+            // barrier -- and issues no fragment reads and no MFMAs, which would only compete with the CU's other workgroup.
+#define LDX_CHUNK_IDLE(NXT, FAR, cc)                                                                               \
+            {                                                                                                      \
+                const uint32_t c_ = (cc);                                                                          \
+                unsigned char *wr = bexp + ((c_ + 1u) & 1u) * kBBuf;                                               \
+                load_b(br[FAR], clampc(c_ + 2u));                                                                  \
+                asm volatile("s_waitcnt vmcnt(1)");   /* in flight: B(c+1), B(c+2) */                              \
+                asm volatile("" : "+v"(br[NXT]));                                                                  \
+                bquarter(wr, br[NXT], 1);                                                                          \
+                bquarter(wr, br[NXT], 2);                                                                          \
+                bquarter(wr, br[NXT], 3);                                                                          \
+                lds_barrier();                                                                                     \
+                asm volatile("s_waitcnt vmcnt(0)");                                                                \
+                asm volatile("" : "+v"(br[FAR]));                                                                  \
+                bquarter(bexp + (c_ & 1u) * kBBuf, br[FAR], 0);                                                    \
+            }
+            if (__builtin_expect(!active, 0)) {   // wave-uniform
+                for (uint32_t c = 0; c < nch_run; c += 3) {
+                    LDX_CHUNK_IDLE(1, 2, c)
+                    if (c + 1 < nch_run) LDX_CHUNK_IDLE(2, 0, c + 1)
+                    if (c + 2 < nch_run) LDX_CHUNK_IDLE(0, 1, c + 2)
+                }
+            } else {
             for (uint32_t c = 0; c < nch_run; c += 3) {   // block-uniform guards: every wave reaches every barrier
                 LDX_CHUNK(0, 1, 2, c)
                 if (c + 1 < nch_run) LDX_CHUNK(1, 2, 0, c + 1)
                 if (c + 2 < nch_run) LDX_CHUNK(2, 0, 1, c + 2)
             }
+            }
 #undef LDX_CHUNK
+#undef LDX_CHUNK_IDLE
             // drain the surplus loads of the last two chunks: their ring registers are about to be reused
             asm volatile("s_waitcnt vmcnt(0)");
             touch_ring(0);
