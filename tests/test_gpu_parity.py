@@ -1086,6 +1086,30 @@ def test_area_repeated_calls_replay_a_graph_and_stay_correct(gpu):
     assert len(small) > 4096 and same(small, again)
 
 
+def test_area_band_beyond_the_plan_limits(gpu):
+    """A chromosome of more than 4096 tiles (524 288 SNPs): the band plan kernel's tile-start table no longer fits its LDS
+    (plain binary search) and the ticket order is not materialised (plain tile order per XCD range); the band's hits still
+    equal the popcount scan's."""
+    import torch
+    from ld_tools_amd import PackedPanel, ld_area, ops, synth
+
+    n, h = 530000, 128
+    p = PackedPanel.from_codes(synth.synth_codes_device(n, h, seed=5))
+    pos = torch.as_tensor(synth.synth_positions(n, step=500)).to(p.device)
+    old = ops.get_area_path()
+    try:
+        ops.set_area_path("fp4")
+        got = ld_area(p, pos, None, 8000, "r_square", 0.6, check_positions=False, use_graph=False)
+        ops.set_area_path("popcount")
+        want = ld_area(p, pos, None, 8000, "r_square", 0.6, check_positions=False, use_graph=False)
+    finally:
+        ops.set_area_path(old)
+    assert len(got) == len(want) and len(got) > 100000
+    assert torch.equal(got.query, want.query) and torch.equal(got.oppos, want.oppos)
+    assert torch.equal(got.ld32.view(torch.int32), want.ld32.view(torch.int32)) and torch.equal(got.offsets, want.offsets)
+    assert got.band_passes > 4096
+
+
 def test_area_rejects_unsorted_positions(gpu):
     from ld_tools_amd import LdxError, PackedPanel, ld_area, synth
 
