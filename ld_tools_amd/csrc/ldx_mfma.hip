@@ -62,6 +62,31 @@ __device__ __forceinline__ void gload8(v2u &dst, const uint2 *p)
 {
     asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(p));
 }
+// The K loop's form: a SCALAR base (the plane + the K-block's offset: SALU) and a 32-bit per-lane byte offset that does not
+// change during a pass -- no 64-bit vector address arithmetic per block (four v_lshl_add_u64 / v_lshlrev_b64 of the block's
+// ~69 VALU instructions) and one address register instead of three pairs.  Planes are < 4 GiB (launch_mfma checks).
+// HAZARD: a VMEM instruction that reads an SGPR which a VALU instruction wrote (v_readlane_b32 reloading a spilled SGPR,
+// v_readfirstlane_b32) needs five wait states in between on gfx9; hipcc inserts them for its own instructions but does not
+// look inside inline asm.  The first form of these loads took the base straight from the compiler and one instantiation
+// (int8 + n11 plane: its bases are reloaded from spill lanes right in front of the loads) read a stale register and
+// faulted.  So the base goes through an s_mov_b64 INSIDE the asm: the VMEM instruction then reads SALU-written registers,
+// which is interlocked.  tests/test_abi_and_host.py scans the shipped code object for the pattern.
+__device__ __forceinline__ void gload16_s(v4u &dst, uint32_t voff, const void *sbase)
+{
+    const void *t;
+    asm volatile("s_mov_b64 %1, %3\n\tglobal_load_dwordx4 %0, %2, %1" : "=v"(dst), "=&s"(t) : "v"(voff), "s"(sbase));
+}
+__device__ __forceinline__ void gload16x2_s(v4u &dst0, v4u &dst1, uint32_t voff, const void *sbase)   // rows r and r + 32
+{
+    const void *t;
+    asm volatile("s_mov_b64 %2, %4\n\tglobal_load_dwordx4 %0, %3, %2\n\tglobal_load_dwordx4 %1, %3, %2 offset:512"
+                 : "=v"(dst0), "=v"(dst1), "=&s"(t) : "v"(voff), "s"(sbase));
+}
+__device__ __forceinline__ void gload8_s(v2u &dst, uint32_t voff, const void *sbase)
+{
+    const void *t;
+    asm volatile("s_mov_b64 %1, %3\n\tglobal_load_dwordx2 %0, %2, %1" : "=v"(dst), "=&s"(t) : "v"(voff), "s"(sbase));
+}
 
 #ifndef LDX_VALU_PER_MFMA
 #define LDX_VALU_PER_MFMA 5   // K loop: VALU slots scheduled behind each MFMA (a step has ~28 VALU for its 8 MFMAs; 5 measured better than 3 or 4)
@@ -260,10 +285,11 @@ __device__ __forceinline__ void store_cell(Cell *p, Cell v)
 template <int kOffset, typename Cell>
 __device__ __forceinline__ void store_cell_saddr(Cell *sbase, uint32_t voff_bytes, Cell v)
 {
+    Cell *t;   // (the base through an s_mov_b64 inside the asm: see gload16_s)
     if constexpr (sizeof(Cell) == 4)
-        asm volatile("global_store_dword %0, %1, %2 offset:%3 nt" : : "v"(voff_bytes), "v"(__builtin_bit_cast(uint32_t, v)), "s"(sbase), "n"(kOffset) : "memory");
+        asm volatile("s_mov_b64 %0, %3\n\tglobal_store_dword %1, %2, %0 offset:%4 nt" : "=&s"(t) : "v"(voff_bytes), "v"(__builtin_bit_cast(uint32_t, v)), "s"(sbase), "n"(kOffset) : "memory");
     else
-        asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3 nt" : : "v"(voff_bytes), "v"(__builtin_bit_cast(unsigned long long, v)), "s"(sbase), "n"(kOffset) : "memory");
+        asm volatile("s_mov_b64 %0, %3\n\tglobal_store_dwordx2 %1, %2, %0 offset:%4 nt" : "=&s"(t) : "v"(voff_bytes), "v"(__builtin_bit_cast(unsigned long long, v)), "s"(sbase), "n"(kOffset) : "memory");
 }
 
 // A lane's four cells of one row -- adjacent in memory (LDX_CELL_OFFSET4 / 8) -- as ONE 16-byte store (two for 8-byte cells),
@@ -273,16 +299,17 @@ __device__ __forceinline__ void store_cell_saddr(Cell *sbase, uint32_t voff_byte
 template <typename Cell>
 __device__ __forceinline__ void store_cells4_saddr(Cell *sbase, uint32_t voff_bytes, Cell c0, Cell c1, Cell c2, Cell c3)
 {
+    Cell *t;   // (the base through an s_mov_b64 inside the asm: see gload16_s)
     if constexpr (sizeof(Cell) == 4) {
         const v4u v = {__builtin_bit_cast(uint32_t, c0), __builtin_bit_cast(uint32_t, c1), __builtin_bit_cast(uint32_t, c2),
                        __builtin_bit_cast(uint32_t, c3)};
-        asm volatile("global_store_dwordx4 %0, %1, %2 nt" : : "v"(voff_bytes), "v"(v), "s"(sbase) : "memory");
+        asm volatile("s_mov_b64 %0, %3\n\tglobal_store_dwordx4 %1, %2, %0 nt" : "=&s"(t) : "v"(voff_bytes), "v"(v), "s"(sbase) : "memory");
     } else {
         const v2u a = __builtin_bit_cast(v2u, c0), b = __builtin_bit_cast(v2u, c1), c = __builtin_bit_cast(v2u, c2),
                   d = __builtin_bit_cast(v2u, c3);
         const v4u lo = {a.x, a.y, b.x, b.y}, hi = {c.x, c.y, d.x, d.y};
-        asm volatile("global_store_dwordx4 %0, %1, %2 nt" : : "v"(voff_bytes), "v"(lo), "s"(sbase) : "memory");
-        asm volatile("global_store_dwordx4 %0, %1, %2 offset:512 nt" : : "v"(voff_bytes), "v"(hi), "s"(sbase) : "memory");   // 64 cells on
+        asm volatile("s_mov_b64 %0, %4\n\tglobal_store_dwordx4 %1, %2, %0 nt\n\tglobal_store_dwordx4 %1, %3, %0 offset:512 nt"   // (64 cells on)
+                     : "=&s"(t) : "v"(voff_bytes), "v"(lo), "v"(hi), "s"(sbase) : "memory");
     }
 }
 
@@ -466,8 +493,6 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
         const uint64_t seg_end = kArea ? tb + (aa.g_end[t] > 2u * t ? aa.g_end[t] - 2u * t : 0u) : (v_end < te ? v_end : te);
         // the j-tile's bits for this thread's expansion share.  int8: row tid/2, 8 bytes (tid%2) of each chunk;
         // FP4: row tid%128, the whole 16 bytes of chunk 2b + tid/128 of K-block b (that lane half's chunk)
-        const uint2 *bsrc = reinterpret_cast<const uint2 *>(alt + (size_t)t * nchunks * kSlab) + tid;
-        constexpr uint32_t kBStride = kSlab * 2u;   // uint2 per chunk
         const uint32_t b_off = kFp4 ? ((tid >> 7) * kSlab + (tid & 127u)) * 16u : (tid >> 1) * kBRow + (tid & 1u) * 64u;
         const uint32_t nblocks = kFp4 ? nchunks / 2u : nchunks;   // K-blocks per unit
 
@@ -570,11 +595,19 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
             typedef std::conditional_t<kFp4, v4u, v2u> bring_t;
             bring_t br[3];   // this thread's bits of the j-tile's K-block (B expansion share): 8 bytes (int8) / 16 bytes (FP4)
             auto clampc = [&](uint32_t c) { return c < nblocks ? c : nblocks - 1u; };   // surplus loads are discarded
+            // per-lane byte offsets from the plane (constant during the pass) + the K-block's scalar offset
+            constexpr uint32_t kBlockBytes = kAStride * 16u;   // one K-block of a slab: 4096 bytes (FP4: two chunks), 2048 (int8)
+            const uint32_t b_voff = kFp4 ? (uint32_t)((((size_t)t * nchunks + (tid >> 7)) * kSlab + (tid & 127u)) * 16u)
+                                         : (uint32_t)(((size_t)t * nchunks * kSlab) * 16u + tid * 8u);
+            const uint32_t a_voff = (uint32_t)((size_t)(ai - alt) * 16u);
+            auto block_base = [&](uint32_t blk) { return reinterpret_cast<const unsigned char *>(alt) + (size_t)blk * kBlockBytes; };
             auto load_b = [&](bring_t &dst, uint32_t blk) {
-                if constexpr (kFp4)
-                    gload16(dst, reinterpret_cast<const v4u *>(alt + ((size_t)t * nchunks + 2u * blk + (tid >> 7)) * kSlab + (tid & 127u)));
-                else
-                    gload8(dst, bsrc + (size_t)blk * kBStride);
+                if constexpr (kFp4) gload16_s(dst, b_voff, block_base(blk));
+                else gload8_s(dst, b_voff, block_base(blk));
+            };
+            auto load_a = [&](v4u (&dst)[MM], uint32_t blk) {
+                if constexpr (MM == 2) gload16x2_s(dst[0], dst[1], a_voff, block_base(blk));
+                else gload16_s(dst[0], a_voff, block_base(blk));
             };
             // quarter q (K step q) of this thread's share of a K-block, expanded into the image at `buf`
             auto bquarter = [&](unsigned char *buf, const bring_t &bits, int q) {
@@ -594,11 +627,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 load_b(w0, 0u);
                 load_b(br[1], clampc(1));
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const v4u *src = reinterpret_cast<const v4u *>(ai + (size_t)clampc(k) * kAStride);
-                    gload16(ar[k][0], src);
-                    if constexpr (MM == 2) gload16_512(ar[k][1], src);
-                }
+                for (int k = 0; k < 2; ++k) load_a(ar[k], clampc(k));
                 asm volatile("s_waitcnt vmcnt(0)");
                 asm volatile("" : "+v"(w0), "+v"(br[1]));
                 touch_ring(0);
@@ -676,11 +705,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 /* loads of K-block c+2, B bits FIRST (vmcnt counts in issue order).  In flight now, oldest first: */ \
                 /* block c+1's {B, A, A} and this batch's {B, A, A}; step 0 needs the former B: 5 may stay */       \
                 load_b(br[FAR], c3);                                                                               \
-                {                                                                                                  \
-                    const v4u *src_ = reinterpret_cast<const v4u *>(ai + (size_t)c3 * kAStride);                   \
-                    gload16(ar[FAR][0], src_);                                                                     \
-                    if constexpr (MM == 2) gload16_512(ar[FAR][1], src_);                                          \
-                }                                                                                                  \
+                load_a(ar[FAR], c3);                                                                               \
                 asm volatile("s_waitcnt vmcnt(%0)" : : "n"(MM == 2 ? 5 : 3));   /* all but the 1 + MM newest pairs */ \
                 asm volatile("" : "+v"(br[NXT]));                                                                  \
                 /* step 0: MFMAs of (c,0); prepare (c,1); quarter 1 of this thread's share of B block c+1 */      \
@@ -1523,6 +1548,10 @@ static int launch_mfma(const void *alt, const double *fa, const double *fr, cons
                        uint32_t *out_n11, hipStream_t s)
 {
     const uint32_t nch = n_chunks(n_hap);
+    if ((uint64_t)n_slabs(n_snps) * nch * kSlab * 16u >= (1ull << 32)) {   // the K loop addresses the plane with 32-bit lane offsets
+        set_error("ld_triangle on the matrix pipe: a bit plane of 4 GiB or more (%u SNPs x %u haplotypes)", n_snps, n_hap);
+        return kNoSlot;   // LDX_PATH_AUTO: the popcount kernel; an explicit matrix-pipe path: LDX_E_UNSUPPORTED
+    }
     const size_t lds = mfma_lds_bytes(kStatRows, kFp4 && !kRaw && !kN11);
     if (lds > 64u * 1024u) {   // above 64 KiB the dynamic LDS size needs the opt-in attribute: once per device
         static std::atomic<uint64_t> opted{0};   // one bit per device ordinal, per instantiation
@@ -1747,6 +1776,10 @@ int area_mfma(const void *alt, const double *fa, const double *fr, const double 
               ldx_hit *hits, uint64_t hit_cap, uint64_t *n_hits, uint32_t *query_counts, void *workspace, bool fp4, hipStream_t s)
 {
     const uint32_t T = n_slabs(n_snps), nch = n_chunks(n_hap);
+    if ((uint64_t)T * nch * kSlab * 16u >= (1ull << 32)) {   // the K loop addresses the plane with 32-bit lane offsets
+        set_error("ld_area on the matrix pipe: a bit plane of 4 GiB or more (%u SNPs x %u haplotypes)", n_snps, n_hap);
+        return kNoSlot;
+    }
     char *w = (char *)workspace;
     uint8_t *is_query = (uint8_t *)w;
     w += ((size_t)n_snps + 255u) / 256u * 256u;

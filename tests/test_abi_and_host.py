@@ -97,6 +97,49 @@ def test_no_packed_fp32_broadcasts_in_shipped_code(tmp_path):
         assert not bad, f"{obj.name}: {bad[:3]}"
 
 
+def test_no_vmem_reads_a_valu_written_sgpr_too_early(tmp_path):
+    """gfx9 hazard: a VMEM instruction that reads an SGPR written by a VALU instruction (v_readlane_b32 reloading a spilled
+    SGPR, v_readfirstlane_b32) needs five wait states in between.  hipcc inserts them for its own instructions, not for
+    inline asm: the kernels' hand-issued loads / stores with a scalar base route it through an s_mov_b64 inside the asm
+    (csrc/ldx_mfma.hip, gload16_s).  Scan the shipped code object for the pattern (round 4: one instantiation read a
+    stale base and faulted)."""
+    import shutil
+    import subprocess
+
+    from ld_tools_amd import _lib
+
+    objdump = Path("/opt/rocm/lib/llvm/bin/llvm-objdump")
+    if not objdump.exists():
+        pytest.skip("llvm-objdump not in this image")
+    shutil.copy(_lib.LIB_PATH, tmp_path / "libldx.so")
+    subprocess.run([str(objdump), "--offloading", "libldx.so"], cwd=tmp_path, capture_output=True, check=True)
+    checked = 0
+    for obj in sorted(tmp_path.glob("libldx.so.*gfx950")):
+        text = subprocess.run([str(objdump), "-d", str(obj)], capture_output=True, text=True, check=True).stdout
+        ins = [ln.split("//")[0].strip() for ln in text.split("\n") if ln.startswith("\t")]
+        for k, ln in enumerate(ins):
+            m = re.match(r"(?:global|buffer|scratch|flat)_\w+ .*?\bs\[(\d+):(\d+)\]", ln)
+            if not m:
+                continue
+            checked += 1
+            lo, hi = int(m.group(1)), int(m.group(2))
+            waited = 0
+            for prev in reversed(ins[max(0, k - 8):k]):
+                if waited >= 5:
+                    break
+                w = re.match(r"v_(?:readlane|readfirstlane)_b32 s(\d+)", prev)
+                assert not (w and lo <= int(w.group(1)) <= hi), f"{obj.name}: `{prev}` {waited} wait states before `{ln}`"
+                d = re.match(r"s_\w+ s(?:(\d+)|\[(\d+):(\d+)\])", prev)      # the last writer is a scalar instruction: interlocked
+                if d and not prev.startswith(("s_cmp", "s_bitcmp", "s_waitcnt", "s_cbranch", "s_branch", "s_nop", "s_barrier")):
+                    dlo = int(d.group(1) or d.group(2))
+                    dhi = int(d.group(1) or d.group(3))
+                    if dlo <= lo and hi <= dhi:
+                        break
+                nop = re.match(r"s_nop (\d+)", prev)
+                waited += int(nop.group(1)) + 1 if nop else 1
+    assert checked > 100   # the scan saw the scalar-base loads and stores
+
+
 def test_geometry_helpers():
     from ld_tools_amd import _lib, dist
 
