@@ -49,19 +49,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
-// global loads the compiler does not track (see the K loop): the caller waits with s_waitcnt vmcnt(N)
-__device__ __forceinline__ void gload16(v4u &dst, const v4u *p)
-{
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p));
-}
-__device__ __forceinline__ void gload16_512(v4u &dst, const v4u *p)   // p + 512 bytes (the rows 32 further down)
-{
-    asm volatile("global_load_dwordx4 %0, %1, off offset:512" : "=v"(dst) : "v"(p));
-}
-__device__ __forceinline__ void gload8(v2u &dst, const uint2 *p)
-{
-    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(p));
-}
+// global loads the compiler does not track (see the K loop): the caller waits with s_waitcnt vmcnt(N).
 // The K loop's form: a SCALAR base (the plane + the K-block's offset: SALU) and a 32-bit per-lane byte offset that does not
 // change during a pass -- no 64-bit vector address arithmetic per block (four v_lshl_add_u64 / v_lshlrev_b64 of the block's
 // ~69 VALU instructions) and one address register instead of three pairs.  Planes are < 4 GiB (launch_mfma checks).
