@@ -642,10 +642,15 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                         const F32Col c32 = f32_col(c.a, c.ra, c.rr, !odd);
                         *reinterpret_cast<v4f *>(ctab32 + tid * 4u) = v4f{c32.a, c32.ra, c32.rr, c32.s};
                     }
-                    if constexpr (kBandF32) {   // the band's float32 screen (area_epilogue): a = ah + al, 10 / sqrt(a r) (inf for a count of 0)
+                    if constexpr (kBandF32) {   // the band's float32 screen (area_epilogue): a = ah + al, and the column's share of
+                        // the threshold, sqrt(k) / s2 with s2 = 10 / sqrt(a r), a hair low; +inf for a count of 0 (r^2 is the int 0
+                        // there: never a hit)
                         float ah, al;
                         f32_split_a((float)c.a, ah, al);
-                        *reinterpret_cast<v4f *>(ctab32 + tid * 4u) = v4f{ah, al, (float)(10.0 * __builtin_sqrt(c.rq)), 0.0f};
+                        const double ar = 1.0 / c.rq;   // a r (0 for a count of 0)
+                        const double kc = aa.k_thres - 2.5;
+                        const double cthr = ar > 0.0 ? 0.1 * __builtin_sqrt((kc > 0.0 ? kc : 0.0) * ar) * (1.0 - 0x1p-20) : __builtin_inf();
+                        *reinterpret_cast<v4f *>(ctab32 + tid * 4u) = v4f{ah, al, (float)cthr, 0.0f};
                     }
                 }
                 const uint32_t i = row0 + (MM == 1 ? l32 : lane);   // a half-height unit has 32 rows: stay inside the padded vectors
@@ -662,9 +667,10 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                     const F32Row r32 = f32_row(r.a_s * 1e-4, r.ra, r.rr, row_ordinary);   // 1e4 a / 1e4: exact (a < 2^32)
                     *reinterpret_cast<v4f *>(rtab32 + lane * 4u) = v4f{r32.a, r32.ra_s, r32.rr_s, r32.s};
                 }
-                if constexpr (kBandF32)
-                    *reinterpret_cast<v4f *>(rtab32 + lane * 4u) =
-                        v4f{(float)(r.a_s * 1e-4), (float)(10.0 * __builtin_sqrt(r.ra * r.rr)), 0.0f, 0.0f};
+                if constexpr (kBandF32) {   // {a, s1 = 10 / sqrt(a r)}; 0 for a count of 0 (such a row is never a candidate)
+                    const double s1 = 10.0 * __builtin_sqrt(r.ra * r.rr);
+                    *reinterpret_cast<v4f *>(rtab32 + lane * 4u) = v4f{(float)(r.a_s * 1e-4), s1 < __builtin_inf() ? (float)s1 : 0.0f, 0.0f, 0.0f};
+                }
                 if (kArea) dst[2] = i < n_snps ? d2{(double)aa.pos[i], (double)(aa.is_query ? aa.is_query[i] : (uint8_t)1)} : d2{0.0, 0.0};
             }
             if (ktok && tid == 0)   // one workgroup per CU in its K loop at a time (see g_sched)
@@ -1180,15 +1186,17 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 };
                 // Float32 screen of a whole step (r^2 thresholds): hits are rare, and the fp64 prefilter below still costs every
                 // (step, column tile) three 16-byte LDS reads per lane and ~7 double-rate instructions per pair.  With this lane's
-                // four columns held in registers as {ah, al, 10 / sqrt(a r)} and the step's two rows read as {a, 10 / sqrt(a r)},
-                // y = ((Dn s1) s2)^2 = 10^4 r^2 costs 7 single-rate instructions per pair (Dn exact through the split column
-                // count, f32_split_a; relative error of y ~1e-6, i.e. < 0.01 of the threshold's units); a step in which no
-                // lane comes within 2.5 units of the threshold -- whatever the pair's validity or window -- is skipped
-                // before any of its fp64 operands are read.  The fp64 prefilter and the full epilogue decide everything else, so
-                // hits are unchanged.  (A count of 0 gives inf or NaN here as there: inf passes, NaN does not.)
+                // four columns held in registers as {ah, al, c = sqrt(k) / s2} and the step's two rows read as {a, s1} (s = 10 /
+                // sqrt(a r)), a pair is within reach of the threshold iff |Dn| s1 >= c, i.e. 10^4 r^2 = (Dn s1 s2)^2 >= k: 5
+                // single-rate instructions per pair (Dn exact through the split column count, f32_split_a; c a hair low and k 2.5
+                // units under the threshold: float32's ~1e-6 is < 0.01 unit); a step in which no lane is within reach --
+                // whatever the pair's window -- is skipped before any of its fp64 operands are read, and only column tiles
+                // with a lane within reach go on to the fp64 prefilter.  The fp64 prefilter and the full epilogue decide
+                // everything else, so hits are unchanged.  (A count of 0 -- r^2 is the int 0, never a hit under a positive
+                // threshold -- is out of reach by construction: s1 = 0 for such a row, c = +inf for such a column.)
                 const bool screen = kBandF32 && prefilter && aa.measure == LDX_MEASURE_RSQ;
                 float sc_ah[4], sc_al[4], sc_s[4];
-                const float sc_n = aa.f32.n, sc_k = (float)(kcand - 0.5);
+                const float sc_n = aa.f32.n;
                 const bool sc_diag = row0 < (t + 1u) * kSlab;      // the unit has cells on or above the diagonal (wave-uniform)
                 const uint32_t t_col0 = t * kSlab + l32;            // this lane's column of the tile's first 32
                 if constexpr (kBandF32) {
@@ -1198,7 +1206,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                             const v4f v = *reinterpret_cast<const v4f *>(ctab32 + (32u * tt + l32) * 4u);
                             sc_ah[tt] = v.x;
                             sc_al[tt] = v.y;
-                            sc_s[tt] = v.z;
+                            sc_s[tt] = v.z;   // the column's share of the threshold
                         }
                     }
                 }
@@ -1266,7 +1274,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                     uint32_t tt_live = 0xFu;   // column tiles of this step that the screen could not rule out (wave-uniform)
                     if constexpr (kBandF32) {
                         if (screen) {
-                            float ymx[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                            float ymx[4] = {-1.0f, -1.0f, -1.0f, -1.0f};
 #pragma unroll
                             for (int m = 0; m < 2; ++m) {
                                 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -1278,18 +1286,18 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
 #pragma unroll
                                 for (int tt = 0; tt < 4; ++tt) dn[tt] = __builtin_fmaf(-rv.x, sc_al[tt], dn[tt]);
 #pragma unroll
-                                for (int tt = 0; tt < 4; ++tt) t[tt] = (dn[tt] * rv.y) * sc_s[tt];
+                                for (int tt = 0; tt < 4; ++tt) t[tt] = __builtin_fmaf(__builtin_fabsf(dn[tt]), rv.y, -sc_s[tt]);   // >= 0: within reach
                                 if (sc_diag) {   // a unit on the diagonal: cells with row <= column mirror real hits (and i == j is r^2 = 1)
 #pragma unroll
-                                    for (int tt = 0; tt < 4; ++tt) t[tt] = row0 + rim > t_col0 + 32u * tt ? t[tt] : 0.0f;
+                                    for (int tt = 0; tt < 4; ++tt) t[tt] = row0 + rim > t_col0 + 32u * tt ? t[tt] : -1.0f;
                                 }
 #pragma unroll
-                                for (int tt = 0; tt < 4; ++tt) ymx[tt] = __builtin_fmaxf(ymx[tt], t[tt] * t[tt]);
+                                for (int tt = 0; tt < 4; ++tt) ymx[tt] = __builtin_fmaxf(ymx[tt], t[tt]);
                             }
-                            if (!__any(__builtin_fmaxf(__builtin_fmaxf(ymx[0], ymx[1]), __builtin_fmaxf(ymx[2], ymx[3])) >= sc_k)) continue;   // wave-uniform
+                            if (!__any(__builtin_fmaxf(__builtin_fmaxf(ymx[0], ymx[1]), __builtin_fmaxf(ymx[2], ymx[3])) >= 0.0f)) continue;   // wave-uniform
                             tt_live = 0u;   // (steps with candidates are rare: four more ballots only here)
 #pragma unroll
-                            for (int tt = 0; tt < 4; ++tt) tt_live |= __any(ymx[tt] >= sc_k) ? 1u << tt : 0u;
+                            for (int tt = 0; tt < 4; ++tt) tt_live |= __any(ymx[tt] >= 0.0f) ? 1u << tt : 0u;
                         }
                     }
                     uint32_t ri[2];
