@@ -410,7 +410,9 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
             }
             return n_tickets;   // every range is exhausted
         } else {
-            return atomicAdd(&sched[0], 1u);
+            // the first gridDim.x tickets are the workgroups' own indices (no atomic round trip before a workgroup's first
+            // pass: ~1.5 us per launch); the counter hands out the rest (the grid never exceeds the tickets: launch_mfma)
+            return gridDim.x + atomicAdd(&sched[0], 1u);
         }
     };
     // this CU's K-loop token: OFF in product builds.  Tuning builds switch it on with LDX_ABLATE bit 4096 to make the
@@ -422,7 +424,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
         ktok = sched + 2u + ((((xcc & 7u) * 8u + ((hw >> 13) & 7u)) * 2u + ((hw >> 12) & 1u)) * 16u + ((hw >> 8) & 15u));
     }
     uint32_t parity = 0;
-    if (tid == 0) tickets[0] = draw();
+    if (tid == 0) tickets[0] = kArea ? draw() : blockIdx.x;
 
     uint64_t hit_slot = 0, hit_slot_end = 0;   // area: this wave's unfilled part of its current batch of hit slots
     uint32_t t_prev = 0xFFFFFFFFu;
