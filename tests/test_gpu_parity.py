@@ -1086,6 +1086,24 @@ def test_area_repeated_calls_replay_a_graph_and_stay_correct(gpu):
     assert len(small) > 4096 and same(small, again)
 
 
+def test_planes_of_4gib_or_more_use_the_popcount_kernels(gpu):
+    """The matrix kernels address the bit plane with 32-bit lane offsets: a plane of 4 GiB or more (3.4 M SNPs x 10 240
+    haplotypes here, zero planes) is LDX_E_UNSUPPORTED on an explicit matrix-pipe path and runs the popcount kernel on auto."""
+    import torch
+    from ld_tools_amd import LdxError, PackedPanel, ld_triangle
+
+    p = PackedPanel.empty(3_400_000, 10240)
+    assert p.alt.numel() >= 1 << 32
+    for path in ("fp4", "mfma"):
+        with pytest.raises(LdxError):
+            ld_triangle(p, unit_range=(0, 16), path=path, fmt="k16")
+    a = ld_triangle(p, unit_range=(0, 16), fmt="k16")
+    b = ld_triangle(p, unit_range=(0, 16), fmt="k16", path="popcount")
+    assert torch.equal(a.cells.view(torch.int32), b.cells.view(torch.int32))
+    del p
+    torch.cuda.empty_cache()
+
+
 def test_area_band_beyond_the_plan_limits(gpu):
     """A chromosome of more than 4096 tiles (524 288 SNPs): the band plan kernel's tile-start table no longer fits its LDS
     (plain binary search) and the ticket order is not materialised (plain tile order per XCD range); the band's hits still
