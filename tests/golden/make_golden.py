@@ -114,10 +114,56 @@ LITERAL = [
 ]
 
 
+# The reference's only real-data known answers: values it PUBLISHES, inverted here to count tuples by
+# running the reference itself over every feasible (a1, a2, n11) with a + r == n.  `n` = haplotypes of the panel the value
+# was made on; the generator asserts that exactly one tuple reproduces all four published numbers.
+#   README.md:168-193      plotly Figure dump, EUR panel (503 samples -> n = 1006), chr6: rs1521 / rs8084 / rs7192
+#   gallery/ld_lite_tabular_output.png   rs10134555 / rs11624464, chr14: r2 0.7807, D' 0.9144, alt_freq 0.5247 / 0.5418.
+#       The panel behind the screenshot is not stated and is NOT the ALL panel: no a / 5008 rounds to 0.5247.  Every even
+#       n <= 5008 was searched once (oracle, then confirmed with the reference here): exactly five n have a solution, each a
+#       unique one; all five are kept as known answers of the function.
+PUBLISHED = [
+    # (source, n, var_1_alt_freq, var_2_alt_freq, r_square, d_prime)   var_1 = the row (larger position), ld_triangle.py:193
+    ("README.md:168-193 rs8084 x rs1521 (EUR)", 1006, 0.5865, 0.7376, 0.0003, 0.0247),
+    ("README.md:168-193 rs7192 x rs1521 (EUR)", 1006, 0.6332, 0.7376, 0.0027, 0.0668),
+    ("README.md:168-193 rs7192 x rs8084 (EUR)", 1006, 0.6332, 0.5865, 0.8216, 1.0),
+] + [(f"gallery/ld_lite_tabular_output.png rs10134555 x rs11624464 (panel unknown; n = {n})", n, 0.5247, 0.5418, 0.7807, 0.9144)
+     for n in (1700, 3160, 3400, 4568, 4860)]
+NO_SOLUTION = [("gallery/ld_lite_tabular_output.png at the ALL panel", 5008, 0.5247, 0.5418, 0.7807, 0.9144)]
+
+
+def invert_published(n, f1, f2, rsq, dp):
+    """Every (n, n11, a1, r1, a2, r2), a + r == n, for which the REFERENCE returns exactly the four published values."""
+    want = {"r_square": rsq, "d_prime": dp, "var_1_alt_freq": f1, "var_2_alt_freq": f2}
+    sols = []
+    for a1 in (a for a in range(n + 1) if round(a / n, 4) == f1):        # calc_ld.py:41,96
+        for a2 in (a for a in range(n + 1) if round(a / n, 4) == f2):
+            # the oracle proposes, the reference disposes: only n11 whose oracle result matches are replayed on lists
+            for n11 in range(max(0, a1 + a2 - n), min(a1, a2) + 1):
+                t = (n, n11, a1, n - a1, a2, n - a2)
+                if orc.ld_from_counts(*t) == want:
+                    sols.append(t)
+            lo, hi = max(0, a1 + a2 - n), min(a1, a2)
+            # ... and the reference is also run on the neighbours of every proposal and on both ends of the range, so a
+            # disagreement between oracle and reference next to a solution would show as a second / missing solution
+            check = {lo, hi} | {m for s in sols for m in (s[1] - 1, s[1], s[1] + 1) if lo <= m <= hi}
+            got = [(n, m, a1, n - a1, a2, n - a2) for m in sorted(check) if ref_counts(n, m, a1, n - a1, a2, n - a2) == want]
+            assert got == [s for s in sols if s[2] == a1 and s[4] == a2], (got, sols)
+    return sols
+
+
 def make_kat():
     tuples = []
     for t in KAT:
         tuples.append({"counts": list(t), "expect": ref_counts(*t)})
+    for src, n, f1, f2, rsq, dp in PUBLISHED:
+        sols = invert_published(n, f1, f2, rsq, dp)
+        assert len(sols) == 1, (src, sols)              # the published numbers pin ONE count tuple
+        exp = ref_counts(*sols[0])
+        assert exp == {"r_square": rsq, "d_prime": dp, "var_1_alt_freq": f1, "var_2_alt_freq": f2}, (src, exp)
+        tuples.append({"counts": list(sols[0]), "expect": exp, "published": src})
+    for src, n, f1, f2, rsq, dp in NO_SOLUTION:
+        assert invert_published(n, f1, f2, rsq, dp) == [], src
     lit = []
     for g1, g2 in LITERAL:
         lit.append({"g1": list(g1), "g2": list(g2), "expect": ref_calc_ld(g1, g2)})

@@ -56,6 +56,26 @@ def test_c_oracle_kat_tuples(kat):
         assert c_oracle.round4(fa1) == e["var_1_alt_freq"] and c_oracle.round4(fa2) == e["var_2_alt_freq"]
 
 
+def test_published_known_answers_are_in_the_fixture(kat):
+    """The reference's only real-data numbers -- README.md:168-193 (EUR, n = 1006: three pairs of chr6) and
+    gallery/ld_lite_tabular_output.png -- are F1 rows: the generator inverts each to its unique count tuple with the
+    reference itself (tests/golden/make_golden.py, PUBLISHED); here both oracles reproduce the printed values."""
+    pub = [t for t in kat["tuples"] if "published" in t]
+    readme = {tuple(t["counts"]): t["expect"] for t in pub if t["published"].startswith("README.md:168-193")}
+    assert readme == {
+        (1006, 439, 590, 416, 742, 264): {"r_square": 0.0003, "d_prime": 0.0247, "var_1_alt_freq": 0.5865, "var_2_alt_freq": 0.7376},
+        (1006, 481, 637, 369, 742, 264): {"r_square": 0.0027, "d_prime": 0.0668, "var_1_alt_freq": 0.6332, "var_2_alt_freq": 0.7376},
+        (1006, 590, 637, 369, 590, 416): {"r_square": 0.8216, "d_prime": 1.0, "var_1_alt_freq": 0.6332, "var_2_alt_freq": 0.5865}}
+    lite = [t for t in pub if t["published"].startswith("gallery/ld_lite_tabular_output.png")]
+    assert sorted(t["counts"][0] for t in lite) == [1700, 3160, 3400, 4568, 4860]
+    for t in lite:
+        assert t["expect"] == {"r_square": 0.7807, "d_prime": 0.9144, "var_1_alt_freq": 0.5247, "var_2_alt_freq": 0.5418}
+    for t in pub:
+        assert orc.ld_from_counts(*t["counts"]) == t["expect"]
+        rnd = c_oracle.ld_from_counts(*t["counts"])
+        assert (rnd[2], rnd[3]) == (t["expect"]["r_square"], t["expect"]["d_prime"])
+
+
 # ------------------------------------------------------------------ F2: exhaustive small n
 def test_py_oracle_small_n(small_n):
     counts = small_n["counts"].astype(np.int64)

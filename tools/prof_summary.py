@@ -59,7 +59,7 @@ if launches:
         if not seen or "triangle" in name or "area" in name or "pack" in name:
             print(line)
 
-for tag in ("pmc_fetch", "pmc_write", "pmc_sq"):
+for tag in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_sq3", "pmc_sq4"):
     acc = defaultdict(lambda: defaultdict(list))
     for f, r in rows(f"{tag}/**/*counter_collection.csv"):
         acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
