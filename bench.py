@@ -589,8 +589,10 @@ def run_rank(args):
     cold_dt, _ = allmax(cold_dt)
     kern_ms_max, kern_ms_min = allmax(kern_ms)
 
-    # the output of the timed region against a separately computed result: nothing was skipped or left stale
-    check = ld_triangle(panel, unit_range=(u0, u1), fmt=fmt)
+    # the output of the timed region against a separately computed result -- by the INDEPENDENT kernel (AND + popcount counts,
+    # fp64 epilogue; the FP4 kernel when popcount itself is timed): nothing was skipped, left stale, or computed wrongly
+    check_path = "popcount" if path != "popcount" else "fp4"
+    check = ld_triangle(panel, unit_range=(u0, u1), fmt=fmt, path=check_path)
     torch.cuda.synchronize()
     if args.debug_corrupt_result and rank == 0:
         out.cells.view(torch.int32).view(-1)[12345] ^= 1
@@ -617,7 +619,12 @@ def run_rank(args):
             nccl_version = "unknown"
     # ---- roofline of the dominant kernel, per launch, this rank's share ----
     my_pairs = n_pairs / world
-    kern_s = kern_ms_max * 1e-3
+    # N = 1: a step IS one launch of the kernel, and `frac` is priced on the interval `value` is computed from (the host's
+    # clock around the K steps between the two fences: ms_per_step); the HIP-event span of the same K launches -- a few
+    # per cent shorter: it excludes the replay's launch and the closing fence -- is printed beside it as
+    # frac_kernel_span.  N > 1: a step also holds the exchange, so the kernel's own events price it.
+    span_s = kern_ms_max * 1e-3
+    kern_s = (dt / args.steps) if not use_dist else span_s
     alg_bytes = float(cell_bytes) * my_pairs + lib.ldx_plane_bytes(n_snps, n_hap)   # result cells + the ALT plane read once
     alg_ops = 2.0 * n_hap * my_pairs                                    # multiply-adds x 2 (2*H per pair)
     lane_ops = 2.0 * math.ceil(n_hap / 32) * my_pairs                   # v_and_b32 + v_bcnt_u32_b32 per 32 haplotypes
@@ -645,7 +652,10 @@ def run_rank(args):
         peak = MFMA_FP4_PEAK_TOPS if path == "fp4" else MFMA_I8_PEAK_TOPS
         roofline = {"bound": "mfma", "achieved": alg_ops / kern_s / 1e12, "peak": peak, "unit": "TOP/s",
                     "frac": alg_ops / kern_s / 1e12 / peak, "traffic": traffic, "traffic_source": traffic_src, **provenance,
-                    "kernel": "triangle_mfma_kernel", "kernel_ms": kern_ms_max, "kernel_ms_min_rank": kern_ms_min,
+                    "kernel": "triangle_mfma_kernel", "kernel_ms": kern_s * 1e3, "kernel_ms_min_rank": kern_ms_min,
+                    "kernel_ms_event_span": kern_ms_max, "frac_kernel_span": alg_ops / span_s / 1e12 / peak,
+                    "interval": ("ms_per_step (host clock around the K graph-replayed launches, the interval of `value`)"
+                                 if not use_dist else "HIP events around each launch on its stream"),
                     "algorithmic_ops": alg_ops, "ops_per_pair": 2 * n_hap,
                     "pipe": ("v_mfma_f32_32x32x64_f8f6f4, FP4 operands (dense peak 10 POP/s)" if path == "fp4"
                              else "v_mfma_i32_32x32x32_i8 (dense peak 5 POP/s)"),
@@ -674,7 +684,8 @@ def run_rank(args):
                    "kernel_path": {"fp4": "FP4 MFMA counts + fp32 / fp64 / mirror epilogue tiers",
                                    "mfma": "int8 MFMA counts + fp64 epilogue",
                                    "popcount": "AND+popcount counts + fp64 epilogue"}[path],
-                   "launch": "HIP graph of the K steps, output verified after the timed region" if graph is not None else "eager",
+                   "launch": (("HIP graph of the K steps" if graph is not None else "eager launches") +
+                              f"; every cell of the timed region's output verified against the {check_path} kernel"),
                    "settle_steps": settle_done,   # untimed, beyond --warmup: the timed region starts at sustained clocks
                    "sharding": "none" if world == 1 else f"row-block shards, all-gather, pass list / {world}",
                    # ranks that met over RCCL (null when the group is not an RCCL group: gloo rehearsals, no group at N = 1)
@@ -712,6 +723,9 @@ def run_rank(args):
         torch.cuda.synchronize()
         ms = a.elapsed_time(c) / reps
         o = {"ms": ms, "pairs_per_s": n_pairs / (ms * 1e-3), "fmt": leg_fmt}
+        if leg_fmt == fmt:      # the same cells as the headline's, from another kernel: compared, every one of them
+            o["results_equal"] = bool(torch.equal(res.cells.view(torch.int32), out.cells.view(torch.int32)))
+            o["verified_against"] = "the timed region's output, every cell"
         if leg_path == "popcount":
             o["frac_of_valu_int_peak"] = lane_ops / (ms * 1e-3) / 1e12 / VALU_PEAK_TLANEOPS
         else:
@@ -725,10 +739,21 @@ def run_rank(args):
         line["other_paths"] = {f"fp4_{other}": leg("fp4", other, reps),
                                "mfma_int8": leg("mfma", fmt, reps),
                                "popcount": leg("popcount", fmt, max(5, reps // 4))}
-        # Independent batches on two streams (two result buffers): what a driver that walks chromosomes or windows gets.
-        # The workgroups of batch k + 1 start while those of batch k drain their last passes.  NOT the headline: `value`
-        # and `roofline` are one launch after the other on one stream.
+        # the headline's cells against an INDEPENDENT kernel on this very box (AND + popcount counts, fp64 epilogue: it
+        # shares neither the counting nor the fp32 tier with the FP4 kernel); a difference ends the run with RC_VERIFY below
+        if line["other_paths"]["mfma_int8"].get("results_equal"):
+            line["config"]["launch"] += " (and the int8 MFMA kernel's timed leg)"
+        # Independent batches on two streams (two result buffers): what a driver that walks chromosomes or tables gets (the
+        # shells' table workers each own a stream).  The workgroups of batch k + 1 start while those of batch k drain their
+        # last passes.  NOT the headline: `value` and `roofline` are one launch after the other on one stream.  Since
+        # round 5 under the headline's own conditions (the leg used to run 20-100 eager-captured batches
+        # right behind the popcount leg, without settling, and read 14 % SLOWER than the headline while the same-box
+        # comparison of tools/gpu_streams.py reads 10 % faster): >= 200 batches per graph, the same settling load, and the
+        # one-stream graph timed beside it in the same loop, interleaved, medians of three.
         try:
+            import statistics
+
+            nb = max(200, args.steps)
             streams = [torch.cuda.Stream(), torch.cuda.Stream()]
             outs = [ld_triangle(panel, fmt=fmt), ld_triangle(panel, fmt=fmt)]
 
@@ -742,31 +767,47 @@ def run_rank(args):
                 for st in streams:
                     cur.wait_stream(st)
 
-            two_streams(max(4, reps // 4))
+            def one_stream(count):
+                for _ in range(count):
+                    ld_triangle(panel, out=out, fmt=fmt)
+
+            two_streams(4)                              # every stream has launched before it is captured
             torch.cuda.synchronize()
-            run2, how = (lambda: two_streams(reps)), "eager launches"
+            runs, how = {"one": (lambda: one_stream(nb)), "two": (lambda: two_streams(nb))}, "eager launches"
             if graph is not None:           # like the headline: the launches as one HIP graph (fork / join across the streams)
                 try:
-                    g2 = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g2):
-                        two_streams(reps)
-                    g2.replay()
-                    torch.cuda.synchronize()
-                    run2, how = g2.replay, "one HIP graph"
+                    gs = {}
+                    for name, fn in (("one", one_stream), ("two", two_streams)):
+                        g2 = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g2):
+                            fn(nb)
+                        g2.replay()
+                        torch.cuda.synchronize()
+                        gs[name] = g2
+                    runs, how = {k: v.replay for k, v in gs.items()}, "one HIP graph each"
                 except Exception:           # noqa: BLE001
                     torch.cuda.synchronize()
+            for _ in range(max(1, int(settle_done / nb))):      # the headline's settling load
+                runs["one"]()
+            torch.cuda.synchronize()
             for o in outs:
                 o.cells.fill_(-1)
-            a, c = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            run2()
-            c.record()
-            torch.cuda.synchronize()
-            ms2 = a.elapsed_time(c) / reps
+            got = {"one": [], "two": []}
+            for _ in range(3):
+                for name in ("one", "two"):
+                    a, c = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    runs[name]()
+                    c.record()
+                    torch.cuda.synchronize()
+                    got[name].append(a.elapsed_time(c) / nb)
+            ms1, ms2 = statistics.median(got["one"]), statistics.median(got["two"])
             same = all(torch.equal(o.cells.view(torch.int32), out.cells.view(torch.int32)) for o in outs)
-            line["other_paths"]["two_streams"] = {"ms_per_batch": ms2, "pairs_per_s": n_pairs / (ms2 * 1e-3), "fmt": fmt,
-                                                      "results_equal": bool(same),
-                                                      "note": f"independent batches alternating on two HIP streams, {how}"}
+            line["other_paths"]["two_streams"] = {
+                "ms_per_batch": ms2, "pairs_per_s": n_pairs / (ms2 * 1e-3), "fmt": fmt, "results_equal": bool(same),
+                "one_stream_same_conditions_ms": ms1, "batches_per_graph": nb, "rounds": 3,
+                "note": f"independent batches alternating on two HIP streams against the same batches on one stream: {how}, "
+                        "interleaved after the headline's settling load, medians"}
             del outs
         except Exception as exc:   # noqa: BLE001  (an extra)
             line["other_paths"]["two_streams"] = {"error": f"{type(exc).__name__}: {exc}"}

@@ -215,13 +215,15 @@ int ldx_triangle_dense_ex_dev(const void *strips, int strips_format, uint32_t n_
  * indices [n_query].  For each query q the opposing set is o != q with
  * max(0, pos_q - flank) < pos_o <= pos_q + flank (pysam fetch semantics, ld_area.py:174-177,
  * 215-217).  var_1 = query, var_2 = opposing (ld_area.py:242-243).  A hit is kept when the
- * ROUNDED measure >= thres (ld_area.py:248).  `queries` must ascend (so their positions do).
+ * ROUNDED measure >= thres (ld_area.py:248).  `queries` must ascend STRICTLY (distinct rows; so their positions ascend):
+ * n_query == n_snps therefore means "every SNP is a query", which the matrix-pipe band takes as such.
  * hits: capacity hit_cap, written in arbitrary order (sort by (query, oppos) for VCF order).
  * Wavefronts reserve hit slots in batches of 256: *n_hits (device uint64) receives the number of
  * slots RESERVED, unused slots carry query == UINT32_MAX and must be skipped.  If *n_hits exceeds
  * hit_cap only the first hit_cap slots were stored: retry with a larger buffer.
  * workspace: ldx_area_workspace_bytes() bytes, 256-byte aligned, scratch for the gathered query
- * panel and the unit plan. */
+ * panel, the unit plan and the band kernel's ticket counters: one workspace per scan in flight (two scans that may run
+ * at the same time -- different streams, or two graphs that hold a scan each -- need two). */
 int ldx_area_dev(const void *alt, const double *fa, const double *fr, const double *q,
                  uint32_t n_snps, uint32_t n_hap, const int64_t *positions,
                  const uint32_t *queries, uint32_t n_query, int64_t flank, int measure,

@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(1024) area_offsets_kernel(const uint32_t *__re
                                                             unsigned long long *__restrict__ summary,
                                                             uint32_t *__restrict__ n_long)
 {
-    if (threadIdx.x == 0) *n_long = 0u;   // the ordering kernels' list of long queries starts empty (no memset node)
+    if (threadIdx.x == 0) store_agent(n_long, 0u);   // the ordering kernels' list of long queries starts empty (no memset node)
     // Exclusive scan of the per-SNP hit counts by ONE workgroup in three barrier-separated phases per chunk of
     // 8192 x 1024 counts: (A) a wave at a time sums 1024-count tiles (every lane its own 64-byte line, the lane
     // totals reduced by shuffles), (B) the tile totals -- a table in LDS -- are scanned by the block, (C) the waves
@@ -357,7 +357,7 @@ __global__ void __launch_bounds__(256) area_block_sums_kernel(const uint32_t *__
                                                               uint32_t *__restrict__ block_tot, uint32_t *__restrict__ n_long)
 {
     __shared__ uint32_t wsum[4];
-    if (blockIdx.x == 0 && threadIdx.x == 0) *n_long = 0u;   // the ordering kernels' list of long queries starts empty
+    if (blockIdx.x == 0 && threadIdx.x == 0) store_agent(n_long, 0u);   // the ordering kernels' list of long queries starts empty
     const uint32_t k0 = blockIdx.x * kScanBlock + threadIdx.x * 4u;
     uint32_t sum = 0;
 #pragma unroll

@@ -31,6 +31,19 @@ __device__ __forceinline__ void block_sync()
     __syncthreads();
 }
 
+// A word that OTHER launches touch with atomics is only ever written with atomics: agent-scope stores go through to the
+// memory side, where the eight XCDs' atomics meet -- a plain store stays in the storing XCD's L2 until a release writes it
+// back.  Round 5 found the ticket counters re-armed with plain stores at the end of a launch still EXHAUSTED for the next
+// launch's atomicAdd: inside a HIP graph whose consecutive kernel nodes share no buffer argument that either writes (two
+// ld_triangle launches into alternating result buffers; the counters live in a __device__ array no argument tracking
+// sees) the runtime chains the nodes without the cache write-back a stream gives -- every launch after the first drew no
+// tickets beyond its static ones and returned a third of the triangle (tools/gpu_streams_dbg.py, profiles/r05/).
+template <typename T>
+__device__ __forceinline__ void store_agent(T *p, T v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Smallest integer k >= 0 with (double)k / 1e4 >= thres: "rounded value >= thres" (ld_area.py:248,
 // ld_triangle.py:224) becomes the exact integer test k >= thres_to_k(thres).
 double thres_to_k(double thres);

@@ -29,6 +29,7 @@
 //     provably rounded like the reference go through the op-for-op mirror.
 // DESIGN.md section 3.1 has the measurements behind each of these choices.
 #include <stdlib.h>
+#include <string.h>
 
 #include <atomic>
 #include <functional>
@@ -68,7 +69,7 @@ __device__ __forceinline__ void gload16x2_s(v4u &dst0, v4u &dst1, uint32_t voff,
 {
     const void *t;
     asm volatile("s_mov_b64 %2, %4\n\tglobal_load_dwordx4 %0, %3, %2\n\tglobal_load_dwordx4 %1, %3, %2 offset:512"
-                 : "=v"(dst0), "=v"(dst1), "=&s"(t) : "v"(voff), "s"(sbase));
+                 : "=&v"(dst0), "=&v"(dst1), "=&s"(t) : "v"(voff), "s"(sbase));   // early-clobber: the second load still reads voff
 }
 __device__ __forceinline__ void gload8_s(v2u &dst, uint32_t voff, const void *sbase)
 {
@@ -190,7 +191,7 @@ __host__ __device__ inline uint32_t mfma_pass_base(uint32_t t, uint32_t n_slabs)
 }
 
 // ticket counters of the dynamic pass scheduler: {next ticket, workgroups finished}; one pair per stream (host side:
-// launch_mfma), zeroed before every launch and re-armed by the last workgroup out
+// acquire_sched), zero when the module is loaded and re-armed by the last workgroup out of every launch
 constexpr uint32_t kSchedSlots = 256;
 // ... followed by one K-loop token per physical CU (indexed by XCC / SE / SH / CU id).  The two workgroups of a CU share
 // each SIMD's matrix pipe, and a workgroup's four waves are tied together by its per-K-block barrier, so whenever the two
@@ -199,8 +200,7 @@ constexpr uint32_t kSchedSlots = 256;
 // per CU into its K loop at a time; the other is in its epilogue (VALU) or waits.  While the epilogue is not shorter
 // than the K loop nobody waits and each K loop has the matrix pipe to itself.
 constexpr uint32_t kCuSlots = 2048;
-constexpr uint32_t kSchedDone = 2u + kCuSlots;   // ... and the sequence number of the last launch that has FINISHED on the slot
-constexpr uint32_t kSchedWords = 3u + kCuSlots;
+constexpr uint32_t kSchedWords = 3u + kCuSlots;   // (the last word is unused since round 5: the finished-launch numbers live in pinned host memory)
 __device__ uint32_t g_sched[kSchedSlots][kSchedWords];
 __device__ unsigned long long g_dbg[8];   // tuning builds (-DLDX_TUNING): event counters, see ldx_debug_counters
 #if defined(LDX_TUNING) && !defined(LDX_STAMPS_ONLY)
@@ -229,6 +229,8 @@ struct AreaArgs {
     int measure;
     F32Const f32;                  // the fp32 epilogue tier's constants (triangle launches use only this member and the next)
     uint32_t launch_seq;           // this launch's number on its ticket-counter slot (acquire_sched): written back when it ends
+    uint32_t *done_host;           // ... into this word of pinned host memory (the slot's entry of PerDevice::done_host); null for
+                                   // the band, whose counters live in the caller's workspace
 };
 constexpr uint32_t kHitBatch = 256;   // hit slots a wave reserves per atomic (as in ldx_area.hip)
 constexpr uint32_t kAreaQueue = 256;  // band: candidate pairs a wave collects before it evaluates them, one per lane
@@ -434,12 +436,16 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
         parity ^= 1u;
         if (ticket >= n_tickets) {   // block-uniform; the last workgroup out re-arms the counters
             if (tid == 0 && atomicAdd(&sched[1], 1u) == gridDim.x - 1u) {
-                sched[1] = 0u;
-                sched[kSchedDone] = aa.launch_seq;   // the host may hand an idle slot to another stream (acquire_sched)
+                // (agent-scope atomic stores, never plain ones: store_agent, ldx_common.h)
+                store_agent(&sched[1], 0u);
                 if (kArea)
-                    for (uint32_t x = 0; x < 8u; ++x) sched[2u + 32u * x] = 0u;   // the per-XCD counters (over-drawn at the end)
+                    for (uint32_t x = 0; x < 8u; ++x) store_agent(&sched[2u + 32u * x], 0u);   // the per-XCD counters (over-drawn at the end)
                 __threadfence();
-                sched[0] = 0u;
+                store_agent(&sched[0], 0u);
+                // the slot is re-armed: tell the host, which may now hand it to another stream (acquire_sched).  A release
+                // store at system scope into pinned host memory: the host compares it with the number it issued, without a
+                // copy or a synchronisation.
+                if (aa.done_host) __hip_atomic_store(aa.done_host, aa.launch_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
             break;
         }
@@ -501,13 +507,18 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
             typedef std::conditional_t<kFp4, v16f, v16i> acc_t;
             typedef std::conditional_t<kFp4, float, int> accel_t;   // one accumulator element: n11 (FP4) or 8 * n11 (int8)
             auto count_of = [](accel_t x) { if constexpr (kFp4) return (uint32_t)x; else return (uint32_t)x >> 3; };
+            // The accumulators are never zeroed by VALU moves (128 v_mov_b32 per unit and wave: one lane-instruction per pair,
+            // 3 % of the short-K kernel's vector instructions): the first K step of a unit runs its MFMAs with the constant 0
+            // as the C operand (mma8 with zero_c, the peeled first K-block below).
             acc_t acc[MM][4];
+#ifdef LDX_AB_VALU_ZERO   // tuning: round 4's form
 #pragma unroll
             for (int m = 0; m < MM; ++m)
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[m][tt][e] = 0;
+#endif
 
             // ---- K loop, software-pipelined at K-step (32 haplotypes) granularity -------------------------
             // During the 8 MFMAs of step s the wave (i) has the B fragments of step s+1 in flight from LDS,
@@ -529,7 +540,13 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                                   : *reinterpret_cast<const v4i *>(buf + (32u * tt + l32) * kBRow + w * 32u + half * 16u);
 #endif
             };
-            auto mma8 = [&](const v4i (&af)[MM], const v4i (&bf)[4]) {
+            auto mma8 = [&](const v4i (&af)[MM], const v4i (&bf)[4], auto zero_c) {   // zero_c: C = 0 instead of the accumulators
+#ifdef LDX_AB_VALU_ZERO
+                constexpr bool kZeroC = false;
+                (void)zero_c;
+#else
+                constexpr bool kZeroC = decltype(zero_c)::value;
+#endif
 #pragma unroll
                 for (int m = 0; m < MM; ++m)
 #pragma unroll
@@ -538,13 +555,20 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                         asm volatile("" : "+v"(acc[m][tt]) : "v"(af[m]), "v"(bf[tt]));   // operands stay live, no work
 #else
                     {
+                        acc_t c_in;
+                        if constexpr (kZeroC) {
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) c_in[e] = 0;   // an inline constant of the instruction, not registers
+                        } else {
+                            c_in = acc[m][tt];
+                        }
                         if constexpr (kFp4) {
                             const v8i a8v = {af[m].x, af[m].y, af[m].z, af[m].w, 0, 0, 0, 0};
                             const v8i b8v = {bf[tt].x, bf[tt].y, bf[tt].z, bf[tt].w, 0, 0, 0, 0};
                             // cbsz = blgp = 4: FP4 operands (4 registers each); scale operands 0 = the unscaled instruction
-                            acc[m][tt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8v, b8v, acc[m][tt], 4, 4, 0, 0, 0, 0);
+                            acc[m][tt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8v, b8v, c_in, 4, 4, 0, 0, 0, 0);
                         } else {
-                            acc[m][tt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[m], bf[tt], acc[m][tt], 0, 0, 0);
+                            acc[m][tt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[m], bf[tt], c_in, 0, 0, 0);
                         }
                     }
 #endif
@@ -691,7 +715,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
 #endif
             // one chunk: ring slot CUR holds its A words, slot NXT the next chunk's (A words and B bits),
             // slot FAR receives chunk c+2
-#define LDX_CHUNK(CUR, NXT, FAR, cc)                                                                               \
+#define LDX_CHUNK(CUR, NXT, FAR, cc, ZEROC)                                                                        \
             {                                                                                                      \
                 const uint32_t c_ = (cc);                                                                          \
                 const unsigned char *rd = bexp + (c_ & 1u) * kBBuf;                                                \
@@ -708,7 +732,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 read_bf(bf1, rd, 1);                                                                               \
                 _Pragma("unroll") for (int m = 0; m < MM; ++m) af1[m] = expand_a(ar[CUR][m].y);               \
                 bquarter(wr, br[NXT], 1);                                                                          \
-                mma8(af0, bf0);                                                                                    \
+                mma8(af0, bf0, std::integral_constant<bool, ZEROC>{});   /* a unit's first MFMAs take C = 0 */     \
                 interleave();                                                                                      \
                 __builtin_amdgcn_sched_barrier(0);                                                                 \
                 LDX_CSTAMP(1)                                                                                      \
@@ -716,7 +740,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 read_bf(bf0, rd, 2);                                                                               \
                 _Pragma("unroll") for (int m = 0; m < MM; ++m) af0[m] = expand_a(ar[CUR][m].z);               \
                 bquarter(wr, br[NXT], 2);                                                                          \
-                mma8(af1, bf1);                                                                                    \
+                mma8(af1, bf1, std::false_type{});                                                                 \
                 interleave();                                                                                      \
                 __builtin_amdgcn_sched_barrier(0);                                                                 \
                 LDX_CSTAMP(2)                                                                                      \
@@ -724,7 +748,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 read_bf(bf1, rd, 3);                                                                               \
                 _Pragma("unroll") for (int m = 0; m < MM; ++m) af1[m] = expand_a(ar[CUR][m].w);               \
                 bquarter(wr, br[NXT], 3);                                                                          \
-                mma8(af0, bf0);                                                                                    \
+                mma8(af0, bf0, std::false_type{});                                                                 \
                 interleave();                                                                                      \
                 __builtin_amdgcn_sched_barrier(0);                                                                 \
                 LDX_CSTAMP(3)                                                                                      \
@@ -739,7 +763,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 read_bf(bf0, wr, 0);                                                                               \
                 _Pragma("unroll") for (int m = 0; m < MM; ++m) af0[m] = expand_a(ar[NXT][m].x);               \
                 bquarter(bexp + (c_ & 1u) * kBBuf, br[FAR], 0);                                                    \
-                mma8(af1, bf1);                                                                                    \
+                mma8(af1, bf1, std::false_type{});                                                                 \
                 interleave();                                                                                      \
                 __builtin_amdgcn_sched_barrier(0);                                                                 \
                 LDX_CSTAMP(5)                                                                                      \
@@ -770,10 +794,11 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                     if (c + 2 < nch_run) LDX_CHUNK_IDLE(0, 1, c + 2)
                 }
             } else {
-            for (uint32_t c = 0; c < nch_run; c += 3) {   // block-uniform guards: every wave reaches every barrier
-                LDX_CHUNK(0, 1, 2, c)
-                if (c + 1 < nch_run) LDX_CHUNK(1, 2, 0, c + 1)
-                if (c + 2 < nch_run) LDX_CHUNK(2, 0, 1, c + 2)
+            LDX_CHUNK(0, 1, 2, 0u, true)                  // the first K-block, peeled: its first step writes the accumulators (C = 0)
+            for (uint32_t c = 1; c < nch_run; c += 3) {   // block-uniform guards: every wave reaches every barrier
+                LDX_CHUNK(1, 2, 0, c, false)
+                if (c + 1 < nch_run) LDX_CHUNK(2, 0, 1, c + 1, false)
+                if (c + 2 < nch_run) LDX_CHUNK(0, 1, 2, c + 2, false)
             }
             }
 #undef LDX_CHUNK
@@ -1435,18 +1460,31 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
 }
 
 // One ticket-counter slot per (device, stream): launches of one stream are ordered, so they may share it; launches of
-// different streams (or devices) may overlap, so they must not.  The slots live in the per-device instance of g_sched;
-// a slot is zeroed on the stream that acquires it, and from then on every launch leaves it re-armed (the last
-// workgroup out resets both words), so a launch costs no memset node.
+// different streams (or devices) may overlap, so they must not.  The slots live in the per-device instance of g_sched,
+// which the loader zero-fills; every launch leaves its slot re-armed (the last workgroup out resets the words with
+// agent-scope atomic stores), so a launch costs no memset node.  (ld_area's band keeps its counters in the caller's
+// workspace instead: area_mfma.)
 // Reclaiming (round 4).  A process that keeps creating streams (one per chromosome, per table ...) runs out of the 256
-// slots of a device.  Every launch carries a sequence number (AreaArgs::launch_seq) that its last workgroup writes back
-// into the slot; when no slot is free the host reads the 256 numbers (one small copy on a private stream) and takes a slot
-// whose last ISSUED launch has FINISHED -- whatever became of the stream that owned it (destroyed, idle, reused) -- and
-// that was never used under stream capture (a captured graph has the slot's address baked into its kernel nodes and may be
-// replayed at any time).  The old owner, should it launch again, simply acquires a slot anew.  Only when all 256 slots are
-// in flight or captured does the call fail: kNoSlot, which the entry points turn into the popcount kernel for
-// LDX_PATH_AUTO (identical results) and into LDX_E_UNSUPPORTED for an explicit matrix-pipe path.
-static int acquire_sched(hipStream_t s, uint32_t **sched, uint32_t *launch_seq)
+// slots of a device.  Every launch carries a sequence number (AreaArgs::launch_seq) that its last workgroup publishes
+// when it ends; when no slot is free the host takes a slot whose last ISSUED launch has FINISHED -- whatever became of
+// the stream that owned it (destroyed, idle, reused) -- and that was never used under stream capture (a captured graph
+// has the slot's address baked into its kernel nodes and may be replayed at any time).  The old owner, should it launch
+// again, simply acquires a slot anew.  Only when all 256 slots are in flight or captured does the call fail: kNoSlot,
+// which the entry points turn into the popcount kernel for LDX_PATH_AUTO (identical results) and into
+// LDX_E_UNSUPPORTED for an explicit matrix-pipe path.
+// Round 5 (ADVICE r04 + VERDICT r04 item 8):
+//   * the finished-launch numbers are published into PINNED HOST memory (one word per slot, a system-scope release store
+//     by the launch's last workgroup), so the host reads them with a plain load -- no copy, no synchronisation;
+//   * a slot's sequence numbers are MONOTONE across owners: a reclaimed slot continues where the last owner stopped.
+//     (Round 4 restarted at 0: the new owner's first launch was number 1 while the host word still said 1 from the old
+//     owner's first launch, so until that launch finished the slot looked idle again and could be handed to a second
+//     stream.)  The number is issued in the same critical section that hands the slot out: there is no window in which
+//     a taken slot compares as finished;
+//   * a map hit is not trusted blindly: stream handles are recycled by the runtime.  If the slot's last launch has NOT
+//     finished while the caller's stream reports no pending work (hipStreamQuery == hipSuccess), that launch cannot have
+//     been issued on the caller's stream -- the handle belonged to a stream that was destroyed with work in flight -- and
+//     the caller gets another slot (the orphan is reclaimed like any other once its launch ends).
+static int acquire_sched(hipStream_t s, uint32_t **sched, uint32_t *launch_seq, uint32_t **done_host)
 {
     struct Key {
         int dev;
@@ -1458,15 +1496,17 @@ static int acquire_sched(hipStream_t s, uint32_t **sched, uint32_t *launch_seq)
     };
     struct Slot {
         hipStream_t owner = nullptr;
-        uint32_t issued = 0;       // sequence number of the last launch issued on the slot
+        uint32_t issued = 0;       // sequence number of the last launch issued on the slot (monotone across owners)
         bool in_use = false;
+        bool owned = false;        // `owner` still maps to this slot (false: an orphan waiting for its launch to end)
         bool captured = false;     // a launch was recorded into a graph: never reclaimed
     };
     struct PerDevice {
         uint32_t (*pool)[kSchedWords] = nullptr;   // this device's g_sched
         Slot slots[kSchedSlots];
         uint32_t next_slot = 0;                    // slots handed out for the first time so far
-        hipStream_t aux = nullptr;                 // private non-blocking stream of the reclaiming copy
+        uint32_t *done = nullptr;                  // [kSchedSlots] pinned host memory: number of the last FINISHED launch
+        uint32_t *done_dev = nullptr;              // ... as the device addresses it
     };
     static std::mutex sched_mutex;
     static std::unordered_map<Key, uint32_t, KeyHash> sched_slot;
@@ -1479,64 +1519,74 @@ static int acquire_sched(hipStream_t s, uint32_t **sched, uint32_t *launch_seq)
         (void)hipGetLastError();
         cap = hipStreamCaptureStatusNone;
     }
-    bool fresh = false;
+    std::lock_guard<std::mutex> lock(sched_mutex);
+    if (!per_dev[dev]) per_dev[dev] = new PerDevice();
+    PerDevice &pd = *per_dev[dev];
+    if (!pd.pool) {
+        void *sym = nullptr;
+        LDX_HIP(hipGetSymbolAddress(&sym, HIP_SYMBOL(g_sched)));   // the current device's copy of the symbol
+        void *host = nullptr, *devp = nullptr;
+        LDX_HIP(hipHostMalloc(&host, kSchedSlots * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
+        memset(host, 0, kSchedSlots * sizeof(uint32_t));
+        LDX_HIP(hipHostGetDevicePointer(&devp, host, 0));
+        pd.done = (uint32_t *)host;
+        pd.done_dev = (uint32_t *)devp;
+        pd.pool = reinterpret_cast<uint32_t (*)[kSchedWords]>(sym);
+    }
+    auto finished = [&](uint32_t k) {   // the slot's last issued launch has ended (acquire: its re-arming stores came first)
+        return __atomic_load_n(&pd.done[k], __ATOMIC_ACQUIRE) == pd.slots[k].issued;
+    };
+    const Key key{dev, s};
     uint32_t slot = 0;
-    {
-        std::lock_guard<std::mutex> lock(sched_mutex);
-        if (!per_dev[dev]) per_dev[dev] = new PerDevice();
-        PerDevice &pd = *per_dev[dev];
-        if (!pd.pool) {
-            void *sym = nullptr;
-            LDX_HIP(hipGetSymbolAddress(&sym, HIP_SYMBOL(g_sched)));   // the current device's copy of the symbol
-            pd.pool = reinterpret_cast<uint32_t (*)[kSchedWords]>(sym);
+    bool have = false;
+    auto it = sched_slot.find(key);
+    if (it != sched_slot.end()) {
+        slot = it->second;
+        have = true;
+        Slot &c = pd.slots[slot];
+        if (cap == hipStreamCaptureStatusNone && !c.captured && !finished(slot)) {
+            const hipError_t q = hipStreamQuery(s);
+            if (q != hipSuccess) (void)hipGetLastError();   // hipErrorNotReady: the launch is the caller's own, still running
+            if (q == hipSuccess && !finished(slot)) {        // idle stream, unfinished launch: a recycled handle
+                c.owned = false;
+                sched_slot.erase(it);
+                have = false;
+            }
         }
-        const Key key{dev, s};
-        auto it = sched_slot.find(key);
-        if (it != sched_slot.end()) {
-            slot = it->second;
-        } else {
-            if (pd.next_slot < kSchedSlots) {
-                slot = pd.next_slot++;
-            } else {   // all handed out: look for one whose last launch has finished
-                if (cap != hipStreamCaptureStatusNone) {   // (no copies or synchronisation while the caller captures)
-                    set_error("ld_triangle on the matrix pipe: no free ticket-counter slot on device %d and the stream is "
-                              "capturing; capture on a stream that has launched before", dev);
-                    return kNoSlot;
-                }
-                if (!pd.aux) LDX_HIP(hipStreamCreateWithFlags(&pd.aux, hipStreamNonBlocking));
-                static thread_local uint32_t done[kSchedSlots];
-                LDX_HIP(hipMemcpy2DAsync(done, sizeof(uint32_t), &pd.pool[0][kSchedDone], kSchedWords * sizeof(uint32_t),
-                                         sizeof(uint32_t), kSchedSlots, hipMemcpyDeviceToHost, pd.aux));
-                LDX_HIP(hipStreamSynchronize(pd.aux));
-                bool found = false;
-                for (uint32_t k = 0; k < kSchedSlots && !found; ++k) {
-                    const Slot &c = pd.slots[k];
-                    if (c.in_use && !c.captured && done[k] == c.issued) {
-                        sched_slot.erase(Key{dev, c.owner});
-                        slot = k;
-                        found = true;
-                    }
-                }
-                if (!found) {
-                    set_error("ld_triangle on the matrix pipe: all %u ticket-counter slots of device %d are in flight or "
-                              "belong to captured graphs", kSchedSlots, dev);
-                    return kNoSlot;
+    }
+    if (!have) {
+        if (pd.next_slot < kSchedSlots) {
+            slot = pd.next_slot++;
+        } else {   // all handed out: look for one whose last launch has finished
+            bool found = false;
+            for (uint32_t k = 0; k < kSchedSlots && !found; ++k) {
+                const Slot &c = pd.slots[k];
+                if (c.in_use && !c.captured && finished(k)) {
+                    if (c.owned) sched_slot.erase(Key{dev, c.owner});
+                    slot = k;
+                    found = true;
                 }
             }
-            pd.slots[slot] = Slot{};
-            pd.slots[slot].owner = s;
-            pd.slots[slot].in_use = true;
-            sched_slot.emplace(key, slot);
-            fresh = true;
+            if (!found) {
+                set_error("ld_triangle on the matrix pipe: all %u ticket-counter slots of device %d are in flight or "
+                          "belong to captured graphs", kSchedSlots, dev);
+                return kNoSlot;
+            }
         }
-        Slot &mine = pd.slots[slot];
-        if (cap != hipStreamCaptureStatusNone) mine.captured = true;
-        *launch_seq = ++mine.issued;
-        *sched = pd.pool[slot];
+        const uint32_t keep = pd.slots[slot].issued;   // monotone across owners
+        pd.slots[slot] = Slot{};
+        pd.slots[slot].issued = keep;
+        pd.slots[slot].owner = s;
+        pd.slots[slot].in_use = true;
+        pd.slots[slot].owned = true;
+        sched_slot.emplace(key, slot);
     }
-    // (a reclaimed slot is all zeros already -- its last launch re-armed it -- except for the done word; zeroing it on the
-    // new owner's stream keeps the two cases one)
-    if (fresh) LDX_HIP(hipMemsetAsync(*sched, 0, kSchedWords * sizeof(uint32_t), s));
+    Slot &mine = pd.slots[slot];
+    if (cap != hipStreamCaptureStatusNone) mine.captured = true;
+    if (++mine.issued == 0u) mine.issued = 1u;   // (0 is what a never-used slot's host word says)
+    *launch_seq = mine.issued;
+    *sched = pd.pool[slot];
+    *done_host = pd.done_dev + slot;
     return LDX_OK;
 }
 
@@ -1595,7 +1645,7 @@ static int launch_mfma(const void *alt, const double *fa, const double *fr, cons
     if (grid < 1) grid = 1;
     uint32_t *sched = nullptr;
     AreaArgs tri_args{};
-    if (int rc = acquire_sched(s, &sched, &tri_args.launch_seq)) return rc;
+    if (int rc = acquire_sched(s, &sched, &tri_args.launch_seq, &tri_args.done_host)) return rc;
     tri_args.f32 = f32_const((double)n_hap);
     int ablate = 0;
     unsigned long long *stamps = nullptr;
@@ -1670,7 +1720,7 @@ __global__ void __launch_bounds__(1024) area_band_plan_kernel(const int64_t *__r
                                                               uint32_t n_query, uint32_t *__restrict__ g_begin,
                                                               uint32_t *__restrict__ g_end, uint32_t *__restrict__ pass_base,
                                                               unsigned long long *__restrict__ n_hits, uint32_t *__restrict__ order,
-                                                              uint32_t *__restrict__ first_base)
+                                                              uint32_t *__restrict__ first_base, uint32_t *__restrict__ sched)
 {
     const uint32_t qmin = queries[0], qmax = queries[n_query - 1u];
     __shared__ unsigned long long carry;
@@ -1683,7 +1733,9 @@ __global__ void __launch_bounds__(1024) area_band_plan_kernel(const int64_t *__r
     const bool coarse = T <= kCoarse;
     if (coarse)
         for (uint32_t k = threadIdx.x; k < T; k += 1024u) tile_pos[k] = pos[k * kSlab];
-    if (threadIdx.x == 0) { carry = 0; pass_base[0] = 0; first_base[0] = 0; *n_hits = 0ull; }   // (the slot counter of the scan that follows: no memset node)
+    if (threadIdx.x == 0) { carry = 0; pass_base[0] = 0; first_base[0] = 0; store_agent(n_hits, 0ull); }   // (the slot counter of the scan that follows: no memset node)
+    // the band kernel's ticket counters (its own words of the workspace: sched[0], sched[1], one per XCD at 2 + 32 x)
+    if (threadIdx.x < 256u) store_agent(&sched[threadIdx.x], 0u);
     block_sync();
     for (uint32_t t0 = 0; t0 < T; t0 += 1024u) {
         const uint32_t t = t0 + threadIdx.x;
@@ -1755,6 +1807,7 @@ __global__ void __launch_bounds__(1024) area_band_plan_kernel(const int64_t *__r
 // room for the band's ticket order: one word per pass of the FULL triangle (what a band can need at most), for panels up
 // to ~512 000 SNPs; beyond that the band keeps plain tile order
 constexpr size_t kOrderCap = 4u << 20;
+constexpr size_t kAreaSchedWords = 256;   // the band's ticket counters inside the workspace: [0], [1], [2 + 32 x] for x < 8
 static size_t area_order_entries(uint32_t n_snps)
 {
     const uint32_t T = n_slabs(n_snps);
@@ -1766,7 +1819,7 @@ size_t area_mfma_workspace_bytes(uint32_t n_snps)
 {
     const size_t T = n_slabs(n_snps);
     return ((size_t)n_snps + 255u) / 256u * 256u + 2u * (((T + 1u) * 4u + 255u) / 256u * 256u) + 2u * ((T * 4u + 255u) / 256u * 256u) +
-           (area_order_entries(n_snps) * 4u + 255u) / 256u * 256u;
+           (area_order_entries(n_snps) * 4u + 255u) / 256u * 256u + kAreaSchedWords * 4u;
 }
 
 int area_mfma(const void *alt, const double *fa, const double *fr, const double *q, uint32_t n_snps, uint32_t n_hap,
@@ -1790,6 +1843,12 @@ int area_mfma(const void *alt, const double *fa, const double *fr, const double 
     uint32_t *first_base = (uint32_t *)w;   // [T + 1] tiles with at least one pass before tile t
     w += (((size_t)T + 1u) * 4u + 255u) / 256u * 256u;
     uint32_t *order = area_order_entries(n_snps) ? (uint32_t *)w : nullptr;
+    w += (area_order_entries(n_snps) * 4u + 255u) / 256u * 256u;
+    // The band's ticket counters: 256 words of THIS call's workspace, zeroed by the plan kernel in front of the band kernel
+    // (round 5, ADVICE r04: they used to be the (device, stream) slot of g_sched, and every ld_area plan graph -- captured
+    // on torch's one shared capture stream -- had the same slot baked in: two plans replayed on two streams at once shared
+    // their counters).  Concurrent scans need distinct workspaces anyway.
+    uint32_t *sched = (uint32_t *)w;
     if (n_query == n_snps) {   // ascending distinct rows: every SNP is a query -- no mask at all
         is_query = nullptr;
     } else {
@@ -1798,7 +1857,7 @@ int area_mfma(const void *alt, const double *fa, const double *fr, const double 
         LDX_HIP(hipGetLastError());
     }
     area_band_plan_kernel<<<1, 1024, 0, s>>>(positions, n_snps, T, flank, queries, n_query, g_begin, g_end, pass_base,
-                                             (unsigned long long *)n_hits, order, first_base);
+                                             (unsigned long long *)n_hits, order, first_base, sched);
     LDX_HIP(hipGetLastError());
     const size_t lds = mfma_lds_bytes(kRows64, false, true);
     {   // above 64 KiB the dynamic LDS size needs the opt-in attribute: once per device
@@ -1814,9 +1873,7 @@ int area_mfma(const void *alt, const double *fa, const double *fr, const double 
         }
     }
     const int cus = device_cus();
-    uint32_t *sched = nullptr;
     AreaArgs aa{};
-    if (int rc = acquire_sched(s, &sched, &aa.launch_seq)) return rc;
     aa.f32 = f32_const((double)n_hap);
     aa.pos = positions;
     aa.is_query = is_query;

@@ -293,7 +293,7 @@ def query_partition(positions, queries, flank: int, world: int) -> List[Tuple[in
     import numpy as np
 
     pos = np.asarray(positions, dtype=np.int64)
-    q = np.arange(pos.size, dtype=np.int64) if queries is None else np.sort(np.asarray(queries, dtype=np.int64))
+    q = np.arange(pos.size, dtype=np.int64) if queries is None else np.unique(np.asarray(queries, dtype=np.int64))
     if q.size == 0:
         return [(0, 0)] * world
     qpos = pos[q]
@@ -346,7 +346,7 @@ def ld_area_sharded(panel, positions, queries=None, flank: int = 100000, measure
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     pos = np.asarray(positions.cpu() if hasattr(positions, "cpu") else positions, dtype=np.int64)
-    q = np.arange(pos.size, dtype=np.int64) if queries is None else np.sort(np.asarray(queries, dtype=np.int64))
+    q = np.arange(pos.size, dtype=np.int64) if queries is None else np.unique(np.asarray(queries, dtype=np.int64))   # strictly ascending, like ops.ld_area
     b, e = query_partition(pos, q, flank, world)[rank]
     mine = ld_area(panel, positions, q[b:e].tolist(), flank, measure, thres)
     if not gather:

@@ -307,6 +307,10 @@ class _AreaPlan:
         self.hits = torch.empty((cap, 4), dtype=torch.int32, device=dev)
         self.graph = None
         self.uses = 0
+        self.nbytes = sum(int(t.numel()) * t.element_size() for t in (self.ws, self.fin, self.raw, self.hits, self.offsets))
+
+
+_PLAN_BYTES_MAX = 1 << 30      # kept ld_area plans per panel (buffers a plan pins while it is kept)
 
 
 def _area_launch(panel, pos, q, nq, flank, measure, thres, plan, events=None):
@@ -345,7 +349,10 @@ def ld_area(panel: PackedPanel, positions, queries: Optional[Sequence[int]] = No
     to size the result.  When the same scan shape comes again -- the same panel, the same DEVICE tensor of positions,
     the same queries / flank / measure / threshold: a driver walking tables of one chromosome -- its launches are
     replayed as ONE HIP graph from the second repetition on (``use_graph``: None = that rule, False = never, True = from the
-    first call); the plan (buffers + graph) lives on the panel.
+    first call); the plan (buffers + graph) lives on the panel and keeps its buffers resident until it is evicted (eight
+    shapes / 1 GiB per panel) or ``panel.clear_area_plans()`` is called.  A plan's graph carries its own ticket counters
+    (in the plan's workspace), so plans of different panels or shapes may be replayed on different streams at once; one
+    plan is one set of buffers -- the SAME shape on the same panel from two threads at once is the caller's to serialise.
     ``events`` (instrumentation, bench.py): a list that receives three torch events of the current stream -- before the
     scan, between the scan and the finishing kernels, after them; forces eager launches.
     """
@@ -374,7 +381,9 @@ def ld_area(panel: PackedPanel, positions, queries: Optional[Sequence[int]] = No
             q = plans["all_rows"] = torch.arange(panel.n_snps, dtype=torch.int32, device=dev)
         q_key = "all"
     else:
-        qn = np.sort(np.asarray(queries, dtype=np.int64))   # the kernel wants ascending rows
+        # the kernels want STRICTLY ascending rows (include/ldx.h): a repeated query is one query -- the reference would write
+        # the same result file twice (ld_area.py:152-292) -- and "as many queries as SNPs" must mean every SNP once
+        qn = np.unique(np.asarray(queries, dtype=np.int64))
         if qn.size == 0:
             e = torch.empty(0, dtype=torch.int64, device=dev)
             return AreaHits(e, e, torch.empty((0, 2), dtype=torch.float32, device=dev), 0,
@@ -395,15 +404,18 @@ def ld_area(panel: PackedPanel, positions, queries: Optional[Sequence[int]] = No
         if plan is None:
             plan = _AreaPlan(panel, nq, cap)
             if key is not None:
-                if len(plans) > 8:                  # a handful of shapes per panel; drop the oldest beyond that
-                    for k in [k for k in plans if k != "all_rows"][:len(plans) - 8]:
-                        del plans[k]
+                # A kept plan pins its buffers (two hit buffers of `cap` 16-byte slots, the workspaces) and, from its second
+                # use, a HIP graph: at most eight shapes and _PLAN_BYTES_MAX bytes per panel, oldest dropped first
+                # (PackedPanel.clear_area_plans() drops them all).
+                kept = [k for k in plans if k != "all_rows"]
+                while kept and (len(kept) >= 8 or sum(plans[k].nbytes for k in kept) + plan.nbytes > _PLAN_BYTES_MAX):
+                    del plans[kept.pop(0)]
                 plans[key] = plan
         plan.uses += 1
         if key is not None and plan.graph is None and (use_graph or plan.uses >= 2) and \
                 not torch.cuda.is_current_stream_capturing():
             try:                                    # capture the launches once; a failure leaves the eager path
-                torch.cuda.synchronize()
+                torch.cuda.current_stream().synchronize()   # this stream only: table workers on other streams keep running
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):   # other threads (the shells' table workers) keep allocating
                     _area_launch(panel, pos, q, nq, flank, measure, thres, plan)

@@ -172,3 +172,7 @@ class PackedPanel:
         check(lib.ldx_alt_freq4_dev(self.acnt.data_ptr(), self.n_snps, self.n_hap, out.data_ptr(),
                                     _stream_ptr()), "ldx_alt_freq4_dev")
         return out
+
+    def clear_area_plans(self) -> None:
+        """Drop the ld_area plans kept on this panel (ops.ld_area: buffers + HIP graph per call shape) and their memory."""
+        self.__dict__.pop("_area_plans", None)

@@ -104,6 +104,27 @@ class Panel:
                            _p(bufs["dp_rnd"]), _p(bufs["flags"]))
         return bufs
 
+    def triangle_band(self, row0, row1, libm_pow=True, want=("n11", "rsq_rnd", "dp_rnd", "flags")):
+        """The same loop for rows [row0, row1) into [row1 - row0][n] arrays (element [i - row0][j], j < i; rest zero):
+        what a test needs to walk a 50 000-SNP triangle band by band from several threads without [n][n] buffers.
+        ldo_triangle addresses cell (i, j) as base[i * n + j]; the base handed over is the band's first element minus
+        row0 * n elements, so only the band's rows are ever touched."""
+        n = self.n_snps
+        kinds = {"n11": np.uint32, "rsq_raw": np.float64, "dp_raw": np.float64, "rsq_rnd": np.float64,
+                 "dp_rnd": np.float64, "flags": np.uint8}
+        bufs, ptrs = {}, []
+        for name, dt in kinds.items():
+            if name in want:
+                a = np.zeros((row1 - row0, n), dtype=dt)
+                bufs[name] = a
+                ptrs.append(C.c_void_p(a.ctypes.data - row0 * n * a.itemsize))
+            else:
+                bufs[name] = None
+                ptrs.append(None)
+        lib().ldo_triangle(_p(self.alt), _p(self.acnt), _p(self.rcnt), C.c_size_t(n), C.c_size_t(self.w64),
+                           C.c_uint32(self.n_hap), C.c_size_t(row0), C.c_size_t(row1), C.c_int(int(libm_pow)), *ptrs)
+        return bufs
+
     def area(self, positions, queries, flank, measure=0, thres=0.8, libm_pow=True, cap=None):
         positions = np.ascontiguousarray(positions, dtype=np.int64)
         queries = np.ascontiguousarray(queries, dtype=np.uint32)

@@ -1,4 +1,4 @@
-"""Worker for tests/test_dist_gloo.py: world_size-2 rehearsal of the sharded triangle on CPU (gloo).
+"""Worker for tests/test_dist_gloo.py: rehearsal of the sharded triangle on CPU (gloo), world size 2 or 8.
 
 Each rank "packs" only its slab shard of a synthetic panel (numpy, in the tiled byte layout of
 include/ldx.h), the shards are all-gathered with ld_tools_amd.dist.gather_shards, every rank checks
@@ -98,8 +98,49 @@ def main():
         pairs = torch.tensor([len(rows)], dtype=torch.int64)
         dist.all_reduce(pairs)
         assert int(pairs) == n_snps * (n_snps - 1) // 2
-    # ld_area hit lists: variable-length shards (one of them empty) gathered in rank order
-    for sizes in ([5, 0], [3, 11], [0, 0], [7, 7]):
+    # configs[3]'s geometry with a real process group (no group larger than 2 had ever run dist.py): 100 000
+    # SNPs -> 782 slabs; over 8 ranks 98, ..., 98, 96 -- the uneven branch of fused_gather_finish -- through the exchange
+    # bench.py uses (PanelPipeline's fused_gather_start / fused_gather_finish, asynchronous), twice through the same staging
+    # buffers; 16 haplotypes keep the plane small (the slab geometry depends on the SNP count only).  Then the unit ranges
+    # of the ranks: contiguous, in rank order, equal within one unit, covering every unit of the triangle once.
+    n_snps, n_hap = 100000, 16
+    parts = ldist.slab_partition(n_snps, world)
+    slabs = [(pe - pb + 127) // 128 for (pb, pe) in parts]
+    assert sum(slabs) == 782 and (world != 8 or slabs == [98] * 7 + [96])
+    b, e = parts[rank]
+    mine = synth.synth_codes_host(e - b, n_hap, seed=5, snp_offset=b) if e > b else np.zeros((0, n_hap), np.int8)
+    slab_bytes = ldist.n_chunks(n_hap) * 128 * 16
+    acnt = np.zeros(slabs[rank] * 128, dtype=np.int32)
+    rcnt = np.zeros(slabs[rank] * 128, dtype=np.int32)
+    acnt[: e - b] = (mine == 1).sum(axis=1)
+    rcnt[: e - b] = (mine == 0).sum(axis=1)
+    local = None if e == b else {"alt": torch.from_numpy(tiled_plane(mine, n_hap)), "acnt": torch.from_numpy(acnt),
+                                 "rcnt": torch.from_numpy(rcnt)}
+    full = {"alt": torch.zeros(782 * slab_bytes, dtype=torch.uint8), "acnt": torch.zeros(782 * 128, dtype=torch.int32),
+            "rcnt": torch.zeros(782 * 128, dtype=torch.int32)}
+    stage = None
+    for _ in range(2):
+        for piece in full.values():
+            piece.zero_()
+        stage, work = ldist.fused_gather_start(local, slabs, slab_bytes, torch.device("cpu"), None, stage, False, async_op=True)
+        ldist.fused_gather_finish(full, stage, slabs, slab_bytes, work)
+    whole = synth.synth_codes_host(n_snps, n_hap, seed=5)
+    assert np.array_equal(full["alt"].numpy(), tiled_plane(whole, n_hap)), "configs[3] geometry: gathered ALT plane"
+    fa = np.zeros(782 * 128, dtype=np.int32)
+    fa[:n_snps] = (whole == 1).sum(axis=1)
+    assert np.array_equal(full["acnt"].numpy(), fa), "configs[3] geometry: gathered counts"
+    units = ldist.unit_partition(n_snps, world)
+    total = ldist.triangle_units(n_snps)
+    mine_u = torch.tensor([units[rank][0], units[rank][1]], dtype=torch.int64)
+    all_u = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(all_u, mine_u)
+    edges = [int(x) for t in all_u for x in t]
+    assert edges[0] == 0 and edges[-1] == total and all(edges[2 * r + 1] == edges[2 * r + 2] for r in range(world - 1))
+    sizes_u = [edges[2 * r + 1] - edges[2 * r] for r in range(world)]
+    assert max(sizes_u) - min(sizes_u) <= 1
+    # ld_area hit lists: variable-length shards (some of them empty) gathered in rank order
+    for pattern in ([5, 0], [3, 11], [0, 0], [7, 7]):
+        sizes = [pattern[r % 2] + (r // 2) * (1 if pattern[r % 2] else 0) for r in range(world)]
         k = sizes[rank]
         base = sum(sizes[:rank])
         q = torch.arange(base, base + k, dtype=torch.int64)

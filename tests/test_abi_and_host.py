@@ -122,6 +122,17 @@ def test_no_vmem_reads_a_valu_written_sgpr_too_early(tmp_path):
             if not m:
                 continue
             checked += 1
+            #  a scalar-base LOAD must not return into its own address register while a second load of the same
+            # asm block still reads it: `global_load_dwordx4 v[a:b], vN, s[..]` with a <= N <= b is only legal for the LAST
+            # load that uses vN (the asm's outputs are early-clobber, so hipcc never allocates it that way)
+            ld = re.match(r"global_load_\w+ v(?:(\d+)|\[(\d+):(\d+)\]), v(\d+), s\[", ln)
+            if ld:
+                dlo_, dhi_ = int(ld.group(1) or ld.group(2)), int(ld.group(1) or ld.group(3))
+                addr = int(ld.group(4))
+                nxt = ins[k + 1] if k + 1 < len(ins) else ""
+                again = re.match(r"global_load_\w+ v(?:\d+|\[\d+:\d+\]), v(\d+), s\[", nxt)
+                assert not (dlo_ <= addr <= dhi_ and again and int(again.group(1)) == addr), \
+                    f"{obj.name}: `{ln}` overwrites the address register `{nxt}` still reads"
             lo, hi = int(m.group(1)), int(m.group(2))
             waited = 0
             for prev in reversed(ins[max(0, k - 8):k]):

@@ -23,6 +23,20 @@ def test_two_rank_gloo_rehearsal():
     assert "GLOO_OK" in r.stdout
 
 
+def test_eight_rank_gloo_rehearsal():
+    """The same worker with a process group of EIGHT (gloo, CPU): small panels whose slabs do not reach every rank (ranks
+    with no rows at all), and configs[3]'s geometry -- 100 000 SNPs, 782 slabs as 98, ..., 98, 96 -- through the
+    asynchronous fused exchange bench.py uses, with the unit ranges of the eight ranks checked against each other.
+    (Eight ranks on ONE card is not something a GPU box of this pool allows -- at most six processes may use the card --
+    so the GPU rehearsal of tests/test_gpu_dist.py runs six: the same uneven-shard code with a real kernel behind it.)"""
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), str(ROOT / "tests" / "_gloo_worker.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(ROOT))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "GLOO_OK" in r.stdout
+
+
 def test_fused_exchange_places_the_shards_of_configs3():
     """BASELINE configs[3] geometry, 100 000 SNPs x 5008 haplotypes over 8 ranks: 782 slabs as 98, ..., 98, 96 -- the
     uneven case of fused_gather_finish (the rank-major concatenation is the full piece followed by padding).  The eight

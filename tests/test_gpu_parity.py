@@ -86,6 +86,34 @@ def check_cells(k_true: np.ndarray, flags_true: np.ndarray, ld32: np.ndarray, k1
     assert np.array_equal(u[rest], k_true[rest].astype(np.int64)), tag
 
 
+def oracle_rows_against_cells(o, res, ld32, n11, bands, workers=8):
+    """Rows [r0, r1) of every band in `bands` -- ALL their cells (row > col) -- against the C oracle (oracle/ld_oracle.c:
+    AND + popcount, then calc_ld.py:33-97 op for op): n11 bit-exact, k of r^2 and D' exact, int-0 flags exact.  The oracle
+    does ~1.5e7 pairs/s per thread and releases the GIL (ctypes), so the bands are spread over a small thread pool.
+    ld32 / n11: host copies of the result's cells (numpy).  Returns the number of cells compared."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(band):
+        r0, r1 = band
+        t = o.triangle_band(r0, r1, libm_pow=True, want=("n11", "rsq_rnd", "dp_rnd", "flags"))   # [r1 - r0][n]
+        counts = np.arange(r0, r1, dtype=np.int64)                       # row i has i cells
+        rows = np.repeat(counts, counts)
+        cols = np.concatenate([np.arange(i, dtype=np.int64) for i in range(r0, r1)])
+        idx = res.cell_index(rows, cols)
+        rb = rows - r0
+        assert np.array_equal(n11[idx], t["n11"][rb, cols]), ("n11", band)
+        cells = ld32[idx]
+        assert np.array_equal(k_of(cells[:, 0]), np.rint(t["rsq_rnd"][rb, cols] * 1e4).astype(np.int64)), ("r_square", band)
+        assert np.array_equal(k_of(cells[:, 1]), np.rint(t["dp_rnd"][rb, cols] * 1e4).astype(np.int64)), ("d_prime", band)
+        assert np.array_equal(flags_of(cells), t["flags"][rb, cols]), ("int-0 flags", band)
+        return len(rows)
+
+    bands = [b for b in bands if b[1] > max(b[0], 1)]
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        return sum(pool.map(one, bands))
+
+
+
 # ------------------------------------------------------------------ packing
 @pytest.mark.parametrize("name", list(PANELS))
 def test_pack_matches_oracle(gpu, name, panel_codes):
@@ -490,7 +518,8 @@ def test_too_many_haplotypes_is_an_error(gpu):
 
 
 def test_triangle_bench_size_against_oracle_rows(gpu, path):
-    """C2 (10 000 x 5008): three bands of rows against the C oracle, plus size-independent properties."""
+    """configs[1] (10 000 x 5008): every cell of the FP4 kernel's triangle against the C oracle (three bands of rows for the
+    two comparison kernels), plus size-independent properties."""
     from ld_tools_amd import PackedPanel, ld_triangle, pair_counts, synth
     from oracle import c_oracle
 
@@ -503,15 +532,13 @@ def test_triangle_bench_size_against_oracle_rows(gpu, path):
     assert np.array_equal(p.alt_counts(), o.acnt)
     ld32 = res.ld32.cpu().numpy()
     n11 = res.n11.cpu().numpy().view(np.uint32)
-    for (r0, r1) in [(1, 40), (5000, 5024), (9990, 10000)]:
-        t = o.triangle(r0, r1, libm_pow=True)
-        rows = np.concatenate([np.full(i, i, dtype=np.int64) for i in range(r0, r1)])
-        cols = np.concatenate([np.arange(i, dtype=np.int64) for i in range(r0, r1)])
-        idx = res.cell_index(rows, cols)
-        assert np.array_equal(n11[idx], t["n11"][rows, cols])
-        assert np.array_equal(k_of(ld32[idx, 0]), np.rint(t["rsq_rnd"][rows, cols] * 1e4).astype(np.int64))
-        assert np.array_equal(k_of(ld32[idx, 1]), np.rint(t["dp_rnd"][rows, cols] * 1e4).astype(np.int64))
-        assert np.array_equal(flags_of(ld32[idx]), t["flags"][rows, cols])
+    if path == "fp4":
+        # the product's kernel: EVERY one of the 49 995 000 cells against the oracle (the full-size configs met
+        # the oracle on row bands only; everything else was kernel against kernel).  ~3.5 s of oracle time per thread.
+        bands = [(r, min(r + 125, n)) for r in range(0, n, 125)]
+        assert oracle_rows_against_cells(o, res, ld32, n11, bands) == n * (n - 1) // 2
+    else:   # the comparison kernels: three bands here, every cell against the FP4 kernel's in the tests below / bench.py
+        assert oracle_rows_against_cells(o, res, ld32, n11, [(1, 40), (5000, 5024), (9990, 10000)]) > 300000
     # properties over ALL cells: total n11 mass equals sum_h C(k_h, 2), k_h = ALT count of haplotype column h
     colsum = (codes == 1).sum(axis=0).astype(np.int64)
     assert int(n11.astype(np.int64).sum()) == int((colsum * (colsum - 1) // 2).sum())
@@ -594,19 +621,13 @@ def test_config4_triangle_50k_x_1008(gpu):
     codes = codes_d.cpu().numpy()
     o = c_oracle.Panel(codes)
     assert np.array_equal(p.alt_counts(), o.acnt) and np.array_equal(p.ref_counts(), o.rcnt)
-    checked = 0
-    for (r0, r1) in [(1, 30), (25000, 25008), (49996, 50000)]:
-        t = o.triangle(r0, r1, libm_pow=True)
-        rows = np.concatenate([np.full(i, i, dtype=np.int64) for i in range(r0, r1)])
-        cols = np.concatenate([np.arange(i, dtype=np.int64) for i in range(r0, r1)])
-        idx = torch.from_numpy(ref.cell_index(rows, cols)).to(ref.ld32.device)
-        ld32 = ref.ld32[idx].cpu().numpy()
-        assert np.array_equal(ref.n11[idx].cpu().numpy().view(np.uint32), t["n11"][rows, cols])
-        assert np.array_equal(k_of(ld32[:, 0]), np.rint(t["rsq_rnd"][rows, cols] * 1e4).astype(np.int64))
-        assert np.array_equal(k_of(ld32[:, 1]), np.rint(t["dp_rnd"][rows, cols] * 1e4).astype(np.int64))
-        assert np.array_equal(flags_of(ld32), t["flags"][rows, cols])
-        checked += len(rows)
-    assert checked > 400000
+    # >= 5 % of the rows, all their cells, against the oracle: 40 rows out of every 750 (2 680 rows, 6.7e7 cells) + both ends
+    ld32_h = ref.ld32.cpu().numpy()
+    n11_h = ref.n11.cpu().numpy().view(np.uint32)
+    bands = [(1, 30), (49996, 50000)] + [(r, min(r + 40, n)) for r in range(30, n, 750)]
+    assert sum(b[1] - b[0] for b in bands) >= 0.05 * n
+    assert oracle_rows_against_cells(o, ref, ld32_h, n11_h, bands) > 6e7
+    del ld32_h, n11_h
     colsum = (codes == 1).sum(axis=0).astype(np.int64)
     assert int(ref.n11.to(torch.int64).sum().item()) == int((colsum * (colsum - 1) // 2).sum())
 
@@ -780,6 +801,123 @@ def test_triangle_on_many_streams(gpu):
         assert torch.equal(o2.ld32.view(torch.int32), ref.view(torch.int32)), k
 
 
+def test_graph_of_launches_into_alternating_buffers(gpu):
+    """Round 5: consecutive kernel nodes of a HIP graph that share no written buffer argument are chained WITHOUT the cache
+    write-back a stream gives between two launches; the ticket counters, re-armed with plain stores, then read as exhausted
+    to the next node's atomics, which computed a third of its triangle (tools/gpu_streams_dbg.py; the sequence below is the
+    one that showed it: the one-stream graph captured BEFORE side streams are used and a fork / join graph is captured).
+    The counters are now only ever written with agent-scope atomics (csrc/ldx_common.h, store_agent)."""
+    import torch
+    from ld_tools_amd import PackedPanel, ld_triangle, synth
+
+    p = PackedPanel.from_codes(synth.synth_codes_device(6000, 5008, seed=4))     # 588 passes: more than the 512 static tickets
+    ref = ld_triangle(p, fmt="k16")
+    outs = [ld_triangle(p, fmt="k16"), ld_triangle(p, fmt="k16")]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+
+    def one(count):
+        for k in range(count):
+            ld_triangle(p, out=outs[k & 1], fmt="k16")
+
+    def two(count):
+        cur = torch.cuda.current_stream()
+        for st in streams:
+            st.wait_stream(cur)
+        for k in range(count):
+            with torch.cuda.stream(streams[k & 1]):
+                ld_triangle(p, out=outs[k & 1], fmt="k16")
+        for st in streams:
+            cur.wait_stream(st)
+
+    graphs = []
+    for fn in (one, two):
+        fn(4)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn(6)
+        g.replay()
+        torch.cuda.synchronize()
+        graphs.append(g)
+    for rnd in range(3):
+        for name, g in zip(("one stream", "two streams"), graphs):
+            for o in outs:
+                o.cells.fill_(-1)
+            torch.cuda.synchronize()
+            g.replay()
+            torch.cuda.synchronize()
+            for k, o in enumerate(outs):
+                assert torch.equal(o.cells, ref.cells), (rnd, name, k)
+
+
+def test_area_plans_replayed_on_two_streams_at_once(gpu):
+    """every ld_area plan graph used to carry the ticket-counter slot of torch's one capture stream, so two plans
+    replayed at the same time on two streams shared their counters.  The band's counters now live in the plan's own
+    workspace: two panels' plans, replayed concurrently from two threads on two streams, keep returning the hits of the
+    popcount scan."""
+    import threading
+
+    import torch
+    from ld_tools_amd import PackedPanel, ld_area, ops, synth
+
+    cases = []
+    for n, seed in ((30000, 11), (24000, 12)):
+        p = PackedPanel.from_codes(synth.synth_codes_device(n, 1008, seed=seed))
+        pos = torch.as_tensor(synth.synth_positions(n, step=500)).to(p.device)
+        ops.set_area_path("popcount")
+        want = ld_area(p, pos, None, 100000, "r_square", 0.8, use_graph=False)
+        ops.set_area_path("auto")
+        for _ in range(2):                                   # the second repetition captures the plan's graph
+            got = ld_area(p, pos, None, 100000, "r_square", 0.8, check_positions=False)
+        assert [pl for k, pl in p._area_plans.items() if k != "all_rows"][0].graph
+        cases.append((p, pos, want, got))
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(p, pos, want):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for rep in range(40):
+                    got = ld_area(p, pos, None, 100000, "r_square", 0.8, check_positions=False)
+                    ok = len(got) == len(want) and torch.equal(got.query, want.query) and torch.equal(got.oppos, want.oppos) \
+                        and torch.equal(got.ld32.view(torch.int32), want.ld32.view(torch.int32))
+                    if not ok:
+                        errors.append((p.n_snps, rep, len(got), len(want)))
+                        return
+        except Exception as exc:   # noqa: BLE001
+            errors.append(repr(exc))
+
+    threads = [threading.Thread(target=worker, args=(p, pos, want)) for p, pos, want, _ in cases]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for p, *_ in cases:
+        p.clear_area_plans()
+        assert "_area_plans" not in p.__dict__
+
+
+def test_area_repeated_queries_are_one_query(gpu, area_path):
+    """a query list with repetitions whose LENGTH equals the number of SNPs must not be mistaken for "every SNP is
+    a query" (the band drops its query mask then); ops.ld_area makes the list strictly ascending (include/ldx.h)."""
+    import torch
+    from ld_tools_amd import PackedPanel, ld_area, synth
+
+    n = 2000
+    p = PackedPanel.from_codes(synth.synth_codes_device(n, 1008, seed=9))
+    pos = torch.as_tensor(synth.synth_positions(n, step=500)).to(p.device)
+    uniq = list(range(0, n, 2))
+    dup = uniq + uniq                                        # n entries, half of the SNPs
+    a = ld_area(p, pos, uniq, 50000, "r_square", 0.3)
+    b = ld_area(p, pos, dup, 50000, "r_square", 0.3)
+    assert len(a) == len(b) > 0 and torch.equal(a.query, b.query) and torch.equal(a.oppos, b.oppos)
+    assert torch.equal(a.ld32.view(torch.int32), b.ld32.view(torch.int32))
+    assert bool((a.query % 2 == 0).all())
+
+
 def test_triangle_on_a_thousand_raw_streams(gpu):
     """a driver that creates a raw hipStream_t per chromosome / table must not run out of ticket-counter
     slots (256 per device).  1 000 streams made with hipStreamCreate (ctypes on libamdhip64: torch recycles a pool of 32,
@@ -842,6 +980,24 @@ def test_triangle_on_a_thousand_raw_streams(gpu):
     for st in streams:
         assert hip.hipStreamDestroy(st) == 0
     print(f"explicit-path launches refused while all slots were busy: {refused} of 20")
+    # every slot has been handed out by now, so a new stream RECLAIMS one.  The new owner's launch sits behind a
+    # long kernel of its own stream (a popcount triangle: no slot involved) when a second new stream asks for a slot: it must
+    # not be handed the one just taken (round 4 restarted a reclaimed slot's sequence numbers, so until the new owner's first
+    # launch had run the slot compared as idle again).  Both launches, and a few more rounds of the same, must be right.
+    for rnd in range(6):
+        sx, sy = ctypes.c_void_p(), ctypes.c_void_p()
+        assert hip.hipStreamCreate(ctypes.byref(sx)) == 0 and hip.hipStreamCreate(ctypes.byref(sy)) == 0
+        blocker = torch.empty_like(bref.k16)
+        ox, oy = torch.full_like(ref.k16, -1), torch.full_like(ref.k16, -1)
+        torch.cuda.synchronize()
+        rc = lib.ldx_triangle_ex_dev(big.alt.data_ptr(), big.fa.data_ptr(), big.fr.data_ptr(), big.q.data_ptr(), big.n_snps,
+                                     big.n_hap, 0, big.n_units, 1, _lib.FORMATS["k16"], blocker.data_ptr(), None, None, sx)   # POPCOUNT: ~ms
+        assert rc == 0
+        assert launch(sx, 3, ox) == 0, lib.ldx_last_error()      # queued behind the blocker, on a reclaimed slot
+        assert launch(sy, 3, oy) == 0, lib.ldx_last_error()      # asks for a slot while that launch has not even started
+        assert hip.hipStreamSynchronize(sx) == 0 and hip.hipStreamSynchronize(sy) == 0
+        assert torch.equal(ox, ref.k16) and torch.equal(oy, ref.k16), rnd
+        assert hip.hipStreamDestroy(sx) == 0 and hip.hipStreamDestroy(sy) == 0
 
 
 def test_triangle_100k_shard_of_eight(gpu):
