@@ -32,6 +32,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <chrono>
 #include <functional>
 #include <mutex>
 #include <type_traits>
@@ -77,6 +78,9 @@ __device__ __forceinline__ void gload8_s(v2u &dst, uint32_t voff, const void *sb
     asm volatile("s_mov_b64 %1, %3\n\tglobal_load_dwordx2 %0, %2, %1" : "=v"(dst), "=&s"(t) : "v"(voff), "s"(sbase));
 }
 
+#ifndef LDX_STEP_UNROLL
+#define LDX_STEP_UNROLL 1   // fp32 tier: steps per trip of the step loop (epilogue_f32)
+#endif
 #ifndef LDX_VALU_PER_MFMA
 #define LDX_VALU_PER_MFMA 5   // K loop: VALU slots scheduled behind each MFMA (a step has ~28 VALU for its 8 MFMAs; 5 measured better than 3 or 4)
 #endif
@@ -223,14 +227,20 @@ struct AreaArgs {
     const uint32_t *order;         // [passes] ticket -> pass (area_band_plan_kernel: per XCD range the tiles' FIRST passes first), or null
     ldx_hit *hits;
     uint32_t *counts;              // [n_snps] or null: hits per query row, counted as they are appended (ldx_area_scan_dev)
-    unsigned long long *n_hits;
-    uint64_t hit_cap;
+    // (two unions: the triangle's two launch-bookkeeping words share the storage of two band-only members -- kernel arguments
+    // live in scalar registers, and two more of them pushed the band kernel's register allocation into spilling INSIDE its
+    // K loop, whose hand-counted s_waitcnt vmcnt a scratch access breaks: tests/test_abi_and_host.py scans for that)
+    union {
+        unsigned long long *n_hits;   // band: the hit-slot counter
+        uint32_t *done_host;          // triangle: where the launch's last workgroup publishes launch_seq (pinned host memory:
+    };                                // the slot's entry of acquire_sched's PerDevice::done)
+    union {
+        uint64_t hit_cap;             // band
+        uint32_t launch_seq;          // triangle: this launch's number on its ticket-counter slot (acquire_sched)
+    };
     double flank, k_thres;
     int measure;
     F32Const f32;                  // the fp32 epilogue tier's constants (triangle launches use only this member and the next)
-    uint32_t launch_seq;           // this launch's number on its ticket-counter slot (acquire_sched): written back when it ends
-    uint32_t *done_host;           // ... into this word of pinned host memory (the slot's entry of PerDevice::done_host); null for
-                                   // the band, whose counters live in the caller's workspace
 };
 constexpr uint32_t kHitBatch = 256;   // hit slots a wave reserves per atomic (as in ldx_area.hip)
 constexpr uint32_t kAreaQueue = 256;  // band: candidate pairs a wave collects before it evaluates them, one per lane
@@ -436,16 +446,22 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
         parity ^= 1u;
         if (ticket >= n_tickets) {   // block-uniform; the last workgroup out re-arms the counters
             if (tid == 0 && atomicAdd(&sched[1], 1u) == gridDim.x - 1u) {
-                // (agent-scope atomic stores, never plain ones: store_agent, ldx_common.h)
+                // (agent-scope atomic stores, never plain ones: store_agent, ldx_common.h.  They go through to the memory side
+                // and are complete when acknowledged, so the order between them needs a wait for the acknowledgement, not a
+                // fence: __threadfence() -- and a release store -- write back the XCD's whole L2, result cells included, at
+                // the end of every launch: +2-3 % at 10 000 SNPs, profiles/r05/kernel_end_ab.log)
                 store_agent(&sched[1], 0u);
                 if (kArea)
                     for (uint32_t x = 0; x < 8u; ++x) store_agent(&sched[2u + 32u * x], 0u);   // the per-XCD counters (over-drawn at the end)
-                __threadfence();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 store_agent(&sched[0], 0u);
-                // the slot is re-armed: tell the host, which may now hand it to another stream (acquire_sched).  A release
-                // store at system scope into pinned host memory: the host compares it with the number it issued, without a
-                // copy or a synchronisation.
-                if (aa.done_host) __hip_atomic_store(aa.done_host, aa.launch_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                // the slot is re-armed: tell the host, which may now hand it to another stream (acquire_sched) -- a
+                // system-scope store into pinned host memory once the stores above are acknowledged: the host compares it
+                // with the number it issued, without a copy or a synchronisation.
+                if constexpr (!kArea) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(aa.done_host, aa.launch_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
             }
             break;
         }
@@ -507,18 +523,20 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
             typedef std::conditional_t<kFp4, v16f, v16i> acc_t;
             typedef std::conditional_t<kFp4, float, int> accel_t;   // one accumulator element: n11 (FP4) or 8 * n11 (int8)
             auto count_of = [](accel_t x) { if constexpr (kFp4) return (uint32_t)x; else return (uint32_t)x >> 3; };
-            // The accumulators are never zeroed by VALU moves (128 v_mov_b32 per unit and wave: one lane-instruction per pair,
-            // 3 % of the short-K kernel's vector instructions): the first K step of a unit runs its MFMAs with the constant 0
-            // as the C operand (mma8 with zero_c, the peeled first K-block below).
+            // The accumulators start at zero -- and no VALU instruction zeroes them: the first K-block is peeled out of the
+            // loop below, so hipcc folds this initialisation into the C operand of the unit's first MFMAs (the inline
+            // constant 0; tests/test_abi_and_host.py looks for them in the shipped code object).  Round 4's form -- the same
+            // loop, not peeled -- cost 128 v_mov_b32 per unit and wave: one lane-instruction per pair, 3 % of the short-K
+            // kernel's vector instructions.  (Leaving the accumulators UNINITIALISED and passing an explicit zero C made the
+            // register allocator spill 80 registers, some of them inside the K loop -- whose hand-counted s_waitcnt vmcnt
+            // a scratch access silently breaks: wrong cells at 0.24 ms instead of 0.14.)
             acc_t acc[MM][4];
-#ifdef LDX_AB_VALU_ZERO   // tuning: round 4's form
 #pragma unroll
             for (int m = 0; m < MM; ++m)
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[m][tt][e] = 0;
-#endif
 
             // ---- K loop, software-pipelined at K-step (32 haplotypes) granularity -------------------------
             // During the 8 MFMAs of step s the wave (i) has the B fragments of step s+1 in flight from LDS,
@@ -540,13 +558,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                                   : *reinterpret_cast<const v4i *>(buf + (32u * tt + l32) * kBRow + w * 32u + half * 16u);
 #endif
             };
-            auto mma8 = [&](const v4i (&af)[MM], const v4i (&bf)[4], auto zero_c) {   // zero_c: C = 0 instead of the accumulators
-#ifdef LDX_AB_VALU_ZERO
-                constexpr bool kZeroC = false;
-                (void)zero_c;
-#else
-                constexpr bool kZeroC = decltype(zero_c)::value;
-#endif
+            auto mma8 = [&](const v4i (&af)[MM], const v4i (&bf)[4]) {
 #pragma unroll
                 for (int m = 0; m < MM; ++m)
 #pragma unroll
@@ -555,20 +567,13 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                         asm volatile("" : "+v"(acc[m][tt]) : "v"(af[m]), "v"(bf[tt]));   // operands stay live, no work
 #else
                     {
-                        acc_t c_in;
-                        if constexpr (kZeroC) {
-#pragma unroll
-                            for (int e = 0; e < 16; ++e) c_in[e] = 0;   // an inline constant of the instruction, not registers
-                        } else {
-                            c_in = acc[m][tt];
-                        }
                         if constexpr (kFp4) {
                             const v8i a8v = {af[m].x, af[m].y, af[m].z, af[m].w, 0, 0, 0, 0};
                             const v8i b8v = {bf[tt].x, bf[tt].y, bf[tt].z, bf[tt].w, 0, 0, 0, 0};
                             // cbsz = blgp = 4: FP4 operands (4 registers each); scale operands 0 = the unscaled instruction
-                            acc[m][tt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8v, b8v, c_in, 4, 4, 0, 0, 0, 0);
+                            acc[m][tt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8v, b8v, acc[m][tt], 4, 4, 0, 0, 0, 0);
                         } else {
-                            acc[m][tt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[m], bf[tt], c_in, 0, 0, 0);
+                            acc[m][tt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[m], bf[tt], acc[m][tt], 0, 0, 0);
                         }
                     }
 #endif
@@ -715,7 +720,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
 #endif
             // one chunk: ring slot CUR holds its A words, slot NXT the next chunk's (A words and B bits),
             // slot FAR receives chunk c+2
-#define LDX_CHUNK(CUR, NXT, FAR, cc, ZEROC)                                                                        \
+#define LDX_CHUNK(CUR, NXT, FAR, cc)                                                                               \
             {                                                                                                      \
                 const uint32_t c_ = (cc);                                                                          \
                 const unsigned char *rd = bexp + (c_ & 1u) * kBBuf;                                                \
@@ -732,7 +737,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 read_bf(bf1, rd, 1);                                                                               \
                 _Pragma("unroll") for (int m = 0; m < MM; ++m) af1[m] = expand_a(ar[CUR][m].y);               \
                 bquarter(wr, br[NXT], 1);                                                                          \
-                mma8(af0, bf0, std::integral_constant<bool, ZEROC>{});   /* a unit's first MFMAs take C = 0 */     \
+                mma8(af0, bf0);                                                                                    \
                 interleave();                                                                                      \
                 __builtin_amdgcn_sched_barrier(0);                                                                 \
                 LDX_CSTAMP(1)                                                                                      \
@@ -740,7 +745,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 read_bf(bf0, rd, 2);                                                                               \
                 _Pragma("unroll") for (int m = 0; m < MM; ++m) af0[m] = expand_a(ar[CUR][m].z);               \
                 bquarter(wr, br[NXT], 2);                                                                          \
-                mma8(af1, bf1, std::false_type{});                                                                 \
+                mma8(af1, bf1);                                                                                    \
                 interleave();                                                                                      \
                 __builtin_amdgcn_sched_barrier(0);                                                                 \
                 LDX_CSTAMP(2)                                                                                      \
@@ -748,7 +753,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 read_bf(bf1, rd, 3);                                                                               \
                 _Pragma("unroll") for (int m = 0; m < MM; ++m) af1[m] = expand_a(ar[CUR][m].w);               \
                 bquarter(wr, br[NXT], 3);                                                                          \
-                mma8(af0, bf0, std::false_type{});                                                                 \
+                mma8(af0, bf0);                                                                                    \
                 interleave();                                                                                      \
                 __builtin_amdgcn_sched_barrier(0);                                                                 \
                 LDX_CSTAMP(3)                                                                                      \
@@ -763,7 +768,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 read_bf(bf0, wr, 0);                                                                               \
                 _Pragma("unroll") for (int m = 0; m < MM; ++m) af0[m] = expand_a(ar[NXT][m].x);               \
                 bquarter(bexp + (c_ & 1u) * kBBuf, br[FAR], 0);                                                    \
-                mma8(af1, bf1, std::false_type{});                                                                 \
+                mma8(af1, bf1);                                                                                    \
                 interleave();                                                                                      \
                 __builtin_amdgcn_sched_barrier(0);                                                                 \
                 LDX_CSTAMP(5)                                                                                      \
@@ -794,11 +799,19 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                     if (c + 2 < nch_run) LDX_CHUNK_IDLE(0, 1, c + 2)
                 }
             } else {
-            LDX_CHUNK(0, 1, 2, 0u, true)                  // the first K-block, peeled: its first step writes the accumulators (C = 0)
-            for (uint32_t c = 1; c < nch_run; c += 3) {   // block-uniform guards: every wave reaches every barrier
-                LDX_CHUNK(1, 2, 0, c, false)
-                if (c + 1 < nch_run) LDX_CHUNK(2, 0, 1, c + 1, false)
-                if (c + 2 < nch_run) LDX_CHUNK(0, 1, 2, c + 2, false)
+            if constexpr (kArea) {   // the band keeps round 4's loop: peeled, its register allocation spills inside the K loop
+                for (uint32_t c = 0; c < nch_run; c += 3) {   // block-uniform guards: every wave reaches every barrier
+                    LDX_CHUNK(0, 1, 2, c)
+                    if (c + 1 < nch_run) LDX_CHUNK(1, 2, 0, c + 1)
+                    if (c + 2 < nch_run) LDX_CHUNK(2, 0, 1, c + 2)
+                }
+            } else {
+                LDX_CHUNK(0, 1, 2, 0u)                        // the first K-block, peeled: its first MFMAs take C = 0 (see `acc` above)
+                for (uint32_t c = 1; c < nch_run; c += 3) {
+                    LDX_CHUNK(1, 2, 0, c)
+                    if (c + 1 < nch_run) LDX_CHUNK(2, 0, 1, c + 1)
+                    if (c + 2 < nch_run) LDX_CHUNK(0, 1, 2, c + 2)
+                }
             }
             }
 #undef LDX_CHUNK
@@ -1019,8 +1032,14 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 }
                 // the sixteen steps, in two instantiations: n <= 4096 needs no error term for the product a1 a2 (ldx_common.h)
                 auto steps = [&](auto small_c) -> bool {
+                // LDX_STEP_UNROLL steps per trip of the loop (1, 2, 4, 8 or 16; the rows of a step are (e & 3) + 8 (e >> 2) + 32 m:
+                // unrolled by 4 the row inside its group of eight is static -- LDS and store offsets become immediates, the
+                // scalar address arithmetic happens once per four steps --, unrolled by 16 the accumulator index is static too)
 #pragma unroll 1
-                for (int e = 0; e < 16; ++e) {
+                for (int e_ = 0; e_ < 16; e_ += LDX_STEP_UNROLL) {
+#pragma unroll
+                for (int r_ = 0; r_ < LDX_STEP_UNROLL; ++r_) {
+                    const int e = e_ + r_;
 #if defined(LDX_TUNING) && defined(LDX_STAMPS_ONLY)
                     if (my_stamps && lane == 0 && npass == 1) my_stamps[6 + 4 * kStampPasses + e] = __builtin_amdgcn_s_memtime();
 #endif
@@ -1064,7 +1083,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                             store_cells4_saddr(row, lane_off_b, cell[m * 4 + 0], cell[m * 4 + 1], cell[m * 4 + 2], cell[m * 4 + 3]);
                         }
                     }
-                    const unsigned long long parked = __ballot(!sure);
+                    const unsigned long long parked = __builtin_amdgcn_ballot_w64(!sure);   // (HIP's __ballot compares an INT with 0: a v_cndmask + v_cmp per step)
                     if (parked) {   // wave-uniform
                         const uint32_t np = (uint32_t)__builtin_popcountll(parked);
                         if (qn + np > kQueueCap) {   // more than the queue holds: the fp64 epilogue redoes the unit
@@ -1081,6 +1100,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                         }
                         qn += np;
                     }
+                }
                 }
 #if defined(LDX_TUNING) && defined(LDX_STAMPS_ONLY)
                     if (my_stamps && lane == 0 && npass == 1) my_stamps[6 + 4 * kStampPasses + 16] = __builtin_amdgcn_s_memtime();
@@ -1321,7 +1341,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
 #pragma unroll
                                 for (int tt = 0; tt < 4; ++tt) ymx[tt] = __builtin_fmaxf(ymx[tt], t[tt]);
                             }
-                            if (!__any(__builtin_fmaxf(__builtin_fmaxf(ymx[0], ymx[1]), __builtin_fmaxf(ymx[2], ymx[3])) >= 0.0f)) continue;   // wave-uniform
+                            if (!__builtin_amdgcn_ballot_w64(__builtin_fmaxf(__builtin_fmaxf(ymx[0], ymx[1]), __builtin_fmaxf(ymx[2], ymx[3])) >= 0.0f)) continue;   // wave-uniform
                             tt_live = 0u;   // (steps with candidates are rare: four more ballots only here)
 #pragma unroll
                             for (int tt = 0; tt < 4; ++tt) tt_live |= __any(ymx[tt] >= 0.0f) ? 1u << tt : 0u;
@@ -1480,10 +1500,15 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
 //     owner's first launch, so until that launch finished the slot looked idle again and could be handed to a second
 //     stream.)  The number is issued in the same critical section that hands the slot out: there is no window in which
 //     a taken slot compares as finished;
-//   * a map hit is not trusted blindly: stream handles are recycled by the runtime.  If the slot's last launch has NOT
-//     finished while the caller's stream reports no pending work (hipStreamQuery == hipSuccess), that launch cannot have
-//     been issued on the caller's stream -- the handle belonged to a stream that was destroyed with work in flight -- and
-//     the caller gets another slot (the orphan is reclaimed like any other once its launch ends).
+//   * a map hit is not trusted on the handle alone: the runtime recycles the handles of destroyed streams, and a stream
+//     destroyed with a launch in flight must not lend its slot to the next stream that happens to get its handle.  If the
+//     slot's last launch has NOT finished while the caller's stream reports no pending work (hipStreamQuery ==
+//     hipSuccess), that launch cannot have been issued on the caller's stream: the caller gets another slot, and the
+//     orphan is reclaimed like any other once its launch has ended.  The query costs ~3.5 us (+11 % on an eager launch of
+//     a 3 000-SNP panel, profiles/r05/kernel_end_ab.log), so it is skipped when the slot's previous launch was issued less
+//     than 50 us ago: no stream can have been destroyed and another created in that time (hipStreamCreate alone takes
+//     longer), and a loop of back-to-back launches never pays it.  (hipStreamGetId would identify the stream object, but
+//     the libamdhip64 that torch 2.10 loads does not export it.)
 static int acquire_sched(hipStream_t s, uint32_t **sched, uint32_t *launch_seq, uint32_t **done_host)
 {
     struct Key {
@@ -1496,6 +1521,7 @@ static int acquire_sched(hipStream_t s, uint32_t **sched, uint32_t *launch_seq, 
     };
     struct Slot {
         hipStream_t owner = nullptr;
+        std::chrono::steady_clock::time_point last{};   // when the last launch was issued (host clock)
         uint32_t issued = 0;       // sequence number of the last launch issued on the slot (monotone across owners)
         bool in_use = false;
         bool owned = false;        // `owner` still maps to this slot (false: an orphan waiting for its launch to end)
@@ -1537,6 +1563,7 @@ static int acquire_sched(hipStream_t s, uint32_t **sched, uint32_t *launch_seq, 
         return __atomic_load_n(&pd.done[k], __ATOMIC_ACQUIRE) == pd.slots[k].issued;
     };
     const Key key{dev, s};
+    const auto now = std::chrono::steady_clock::now();
     uint32_t slot = 0;
     bool have = false;
     auto it = sched_slot.find(key);
@@ -1544,7 +1571,8 @@ static int acquire_sched(hipStream_t s, uint32_t **sched, uint32_t *launch_seq, 
         slot = it->second;
         have = true;
         Slot &c = pd.slots[slot];
-        if (cap == hipStreamCaptureStatusNone && !c.captured && !finished(slot)) {
+        if (cap == hipStreamCaptureStatusNone && !c.captured && !finished(slot) &&
+            now - c.last > std::chrono::microseconds(50)) {
             const hipError_t q = hipStreamQuery(s);
             if (q != hipSuccess) (void)hipGetLastError();   // hipErrorNotReady: the launch is the caller's own, still running
             if (q == hipSuccess && !finished(slot)) {        // idle stream, unfinished launch: a recycled handle
@@ -1583,6 +1611,7 @@ static int acquire_sched(hipStream_t s, uint32_t **sched, uint32_t *launch_seq, 
     }
     Slot &mine = pd.slots[slot];
     if (cap != hipStreamCaptureStatusNone) mine.captured = true;
+    mine.last = now;
     if (++mine.issued == 0u) mine.issued = 1u;   // (0 is what a never-used slot's host word says)
     *launch_seq = mine.issued;
     *sched = pd.pool[slot];

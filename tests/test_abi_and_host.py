@@ -151,6 +151,62 @@ def test_no_vmem_reads_a_valu_written_sgpr_too_early(tmp_path):
     assert checked > 100   # the scan saw the scalar-base loads and stores
 
 
+def test_no_scratch_access_inside_the_hand_counted_load_windows(tmp_path):
+    """The matrix kernels issue their K-loop loads in inline asm and wait for them with hand-counted `s_waitcnt vmcnt(N)`
+    (csrc/ldx_mfma.hip); gfx9 counts EVERY vector-memory operation of a wave in that one counter, so a register spill the
+    compiler places inside such a window (a scratch_load / scratch_store it does not know it must not add) shifts the count
+    and a fragment is used before it has arrived -- wrong cells, silently.  Round 5 met it twice while editing the kernel
+    (an explicit zero C operand: 80 spilled registers; two more scalar kernel arguments: the band kernel).  In every
+    instantiation of triangle_mfma_kernel in the shipped code object: no scratch access between the last `vmcnt(0)` in front
+    of a K loop's first MFMA and its last MFMA.  Also: the triangle instantiations start their
+    accumulators through the C operand of the first MFMAs (the inline constant 0), not with 128 VALU moves."""
+    import shutil
+    import subprocess
+
+    from ld_tools_amd import _lib
+
+    objdump = Path("/opt/rocm/lib/llvm/bin/llvm-objdump")
+    if not objdump.exists():
+        pytest.skip("llvm-objdump not in this image")
+    shutil.copy(_lib.LIB_PATH, tmp_path / "libldx.so")
+    subprocess.run([str(objdump), "--offloading", "libldx.so"], cwd=tmp_path, capture_output=True, check=True)
+    seen, zero_c = 0, {}
+    for obj in sorted(tmp_path.glob("libldx.so.*gfx950")):
+        text = subprocess.run([str(objdump), "-d", str(obj)], capture_output=True, text=True, check=True).stdout
+        funcs, cur = {}, None
+        for ln in text.split("\n"):
+            m = re.match(r"^[0-9a-f]+ <(.*)>:$", ln)
+            if m:
+                cur = funcs.setdefault(m.group(1), [])
+            elif ln.startswith("\t") and cur is not None:
+                cur.append(ln.split("//")[0].strip())
+        for name, ins in funcs.items():
+            if "triangle_mfma_kernel" not in name:
+                continue
+            mf = [k for k, x in enumerate(ins) if x.startswith("v_mfma")]
+            assert mf, name
+            clusters = []
+            for k in mf:
+                if clusters and k - clusters[-1][1] < 300:
+                    clusters[-1][1] = k
+                else:
+                    clusters.append([k, k])
+            drains = [k for k, x in enumerate(ins) if re.match(r"s_waitcnt (?:.*\s)?vmcnt\(0\)", x)]
+            for a, b in clusters:
+                # The window: from the loads at the top of the first K-block (behind the prologue's full drain, at most 100
+                # instructions in front of the first MFMA) to the loop's last MFMA.  Behind it only FULL drains follow
+                # (`vmcnt(0)` covers whatever is in flight, a reload included), so a reload at the loop's exit is harmless.
+                lo = max(max([k for k in drains if k < a], default=0), a - 100)
+                hi = b
+                bad = [(k, ins[k]) for k in range(lo, hi + 1) if ins[k].startswith("scratch_")]
+                assert not bad, f"{name[:70]}: scratch access inside a hand-counted window: {bad[:4]}"
+                seen += 1
+            zero_c[name] = sum(1 for k in mf if re.search(r"\], 0(?: |$)", ins[k]))
+    assert seen >= 14                                   # every instantiation's K loops were looked at
+    tri_fp4 = [n for n in zero_c if "Lb0ELb1E" in n.split("triangle_mfma_kernelI")[1][:24] and "ILb0ELb0ELb0ELb1E" in n]
+    assert tri_fp4 and all(zero_c[n] >= 12 for n in tri_fp4), {n[:60]: zero_c[n] for n in tri_fp4}   # 8 (64-row unit) + 4 (half-height)
+
+
 def test_geometry_helpers():
     from ld_tools_amd import _lib, dist
 

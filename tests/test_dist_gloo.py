@@ -27,8 +27,9 @@ def test_eight_rank_gloo_rehearsal():
     """The same worker with a process group of EIGHT (gloo, CPU): small panels whose slabs do not reach every rank (ranks
     with no rows at all), and configs[3]'s geometry -- 100 000 SNPs, 782 slabs as 98, ..., 98, 96 -- through the
     asynchronous fused exchange bench.py uses, with the unit ranges of the eight ranks checked against each other.
-    (Eight ranks on ONE card is not something a GPU box of this pool allows -- at most six processes may use the card --
-    so the GPU rehearsal of tests/test_gpu_dist.py runs six: the same uneven-shard code with a real kernel behind it.)"""
+    (Eight ranks on ONE card is not something a GPU box of this pool allows -- at most six processes may have the card
+    open, the test runner included -- so the GPU rehearsal of tests/test_gpu_dist.py runs four: the same uneven-shard
+    code with a real kernel behind it.)"""
     env = dict(os.environ, OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), str(ROOT / "tests" / "_gloo_worker.py")]

@@ -538,7 +538,7 @@ def test_triangle_bench_size_against_oracle_rows(gpu, path):
         bands = [(r, min(r + 125, n)) for r in range(0, n, 125)]
         assert oracle_rows_against_cells(o, res, ld32, n11, bands) == n * (n - 1) // 2
     else:   # the comparison kernels: three bands here, every cell against the FP4 kernel's in the tests below / bench.py
-        assert oracle_rows_against_cells(o, res, ld32, n11, [(1, 40), (5000, 5024), (9990, 10000)]) > 300000
+        assert oracle_rows_against_cells(o, res, ld32, n11, [(1, 40), (5000, 5024), (9990, 10000)]) > 200000
     # properties over ALL cells: total n11 mass equals sum_h C(k_h, 2), k_h = ALT count of haplotype column h
     colsum = (codes == 1).sum(axis=0).astype(np.int64)
     assert int(n11.astype(np.int64).sum()) == int((colsum * (colsum - 1) // 2).sum())

@@ -1,5 +1,4 @@
 #!/bin/bash
 set -u
 mkdir -p gpurun_out
-timeout -k 10 300 python tools/gpu_streams.py 10000 5008 200 3 > gpurun_out/streams_10k_fixed.log 2>&1; echo "[streams 10k] $?"; grep -v amdgpu.ids gpurun_out/streams_10k_fixed.log | tail -8
-timeout -k 10 1000 python -m pytest tests -m gpu -q -x > gpurun_out/pytest_gpu.log 2>&1; echo "[pytest] $?"; tail -8 gpurun_out/pytest_gpu.log
+LIBS="libldx_base libldx_r5b libldx libldx_u4 libldx_u16" ROUNDS=3 SHAPES="10000 5008 fp4 200 k16|3000 5008 fp4 400 k16|40000 5008 fp4 10 k16|50000 1008 fp4 10 k16" PMC=1 bash tools/gpu_abx.sh > gpurun_out/abx_unroll.log 2>&1; grep -v "^\[pmc" gpurun_out/abx_unroll.log | tail -80
