@@ -523,13 +523,6 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
             typedef std::conditional_t<kFp4, v16f, v16i> acc_t;
             typedef std::conditional_t<kFp4, float, int> accel_t;   // one accumulator element: n11 (FP4) or 8 * n11 (int8)
             auto count_of = [](accel_t x) { if constexpr (kFp4) return (uint32_t)x; else return (uint32_t)x >> 3; };
-            // The accumulators start at zero -- and no VALU instruction zeroes them: the first K-block is peeled out of the
-            // loop below, so hipcc folds this initialisation into the C operand of the unit's first MFMAs (the inline
-            // constant 0; tests/test_abi_and_host.py looks for them in the shipped code object).  Round 4's form -- the same
-            // loop, not peeled -- cost 128 v_mov_b32 per unit and wave: one lane-instruction per pair, 3 % of the short-K
-            // kernel's vector instructions.  (Leaving the accumulators UNINITIALISED and passing an explicit zero C made the
-            // register allocator spill 80 registers, some of them inside the K loop -- whose hand-counted s_waitcnt vmcnt
-            // a scratch access silently breaks: wrong cells at 0.24 ms instead of 0.14.)
             acc_t acc[MM][4];
 #pragma unroll
             for (int m = 0; m < MM; ++m)
@@ -799,18 +792,26 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                     if (c + 2 < nch_run) LDX_CHUNK_IDLE(0, 1, c + 2)
                 }
             } else {
-            if constexpr (kArea) {   // the band keeps round 4's loop: peeled, its register allocation spills inside the K loop
-                for (uint32_t c = 0; c < nch_run; c += 3) {   // block-uniform guards: every wave reaches every barrier
-                    LDX_CHUNK(0, 1, 2, c)
-                    if (c + 1 < nch_run) LDX_CHUNK(1, 2, 0, c + 1)
-                    if (c + 2 < nch_run) LDX_CHUNK(2, 0, 1, c + 2)
-                }
-            } else {
-                LDX_CHUNK(0, 1, 2, 0u)                        // the first K-block, peeled: its first MFMAs take C = 0 (see `acc` above)
+            // Round 5 tried PEELING the first K-block out of this loop, so that hipcc folds the accumulators' zero
+            // initialisation into the C operand of the unit's first MFMAs (128 v_mov_b32 per unit and wave less: one
+            // lane-instruction per pair).  It does fold them -- and the kernel got SLOWER where a launch is a few rounds of
+            // passes: +3.2 % at 8 000 SNPs, +2.7 % at 10 000, nothing at 40 000 or at 50 000 x 1008
+            // (profiles/r05/peeled_first_k_block_ab.log: same box, interleaved, three rounds; -DLDX_AB_PEEL builds it).
+#ifdef LDX_AB_PEEL
+            if constexpr (!kArea) {
+                LDX_CHUNK(0, 1, 2, 0u)
                 for (uint32_t c = 1; c < nch_run; c += 3) {
                     LDX_CHUNK(1, 2, 0, c)
                     if (c + 1 < nch_run) LDX_CHUNK(2, 0, 1, c + 1)
                     if (c + 2 < nch_run) LDX_CHUNK(0, 1, 2, c + 2)
+                }
+            } else
+#endif
+            {
+                for (uint32_t c = 0; c < nch_run; c += 3) {   // block-uniform guards: every wave reaches every barrier
+                    LDX_CHUNK(0, 1, 2, c)
+                    if (c + 1 < nch_run) LDX_CHUNK(1, 2, 0, c + 1)
+                    if (c + 2 < nch_run) LDX_CHUNK(2, 0, 1, c + 2)
                 }
             }
             }
@@ -1083,7 +1084,11 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                             store_cells4_saddr(row, lane_off_b, cell[m * 4 + 0], cell[m * 4 + 1], cell[m * 4 + 2], cell[m * 4 + 3]);
                         }
                     }
+#ifdef LDX_AB_OLD_BALLOT
+                    const unsigned long long parked = __ballot(!sure);
+#else
                     const unsigned long long parked = __builtin_amdgcn_ballot_w64(!sure);   // (HIP's __ballot compares an INT with 0: a v_cndmask + v_cmp per step)
+#endif
                     if (parked) {   // wave-uniform
                         const uint32_t np = (uint32_t)__builtin_popcountll(parked);
                         if (qn + np > kQueueCap) {   // more than the queue holds: the fp64 epilogue redoes the unit
@@ -1826,10 +1831,27 @@ __global__ void __launch_bounds__(1024) area_band_plan_kernel(const int64_t *__r
         }
         const uint32_t pb = pass_base[t], cnt = pass_base[t + 1u] - pb;
         if (!cnt) continue;
-        const uint32_t r0 = pass_base[a], nfirst = first_base[b] - first_base[a], kf = first_base[t] - first_base[a];
+        const uint32_t r0 = pass_base[a];
+#ifdef LDX_AB_FIRST_FIRST   // round 4's order: all first passes of the range, then all the others (each range swept twice)
+        const uint32_t nfirst = first_base[b] - first_base[a], kf = first_base[t] - first_base[a];
         order[r0 + kf] = pb;
         const uint32_t lt = (pb - r0) - kf;   // passes other than first ones before this tile, inside the range
         for (uint32_t i = 1; i < cnt; ++i) order[r0 + nfirst + lt + (i - 1u)] = pb + i;
+#else
+        // Round 5: ONE sweep per range.  A tile's first pass is still handed out early -- kLead tiles ahead of the tile whose
+        // other passes are being handed out, i.e. while the rows of ITS diagonal are inside the band that is streaming
+        // through the XCD's L2 anyway (a +-flank window is ~kLead tiles high at the bench's geometry) -- and the range still
+        // ends with short items (the last kLead tiles' other passes).  Sequence: the first passes of tiles [a, a + kLead);
+        // then for c = a, a + 1, ...: the first pass of tile c + kLead, the other passes of tile c.  With F(t) / L(t) = first /
+        // other passes of the range before tile t:  first pass of t at F(t) + L(max(t - kLead, a)); other pass i of t at
+        // F(min(t + kLead + 1, b)) + L(t) + i - 1.
+        constexpr uint32_t kLead = 8;
+        auto F = [&](uint32_t tt) { return first_base[tt] - first_base[a]; };
+        auto L = [&](uint32_t tt) { return (pass_base[tt] - r0) - F(tt); };
+        order[r0 + F(t) + L(t >= a + kLead ? t - kLead : a)] = pb;
+        const uint32_t ahead = t + kLead + 1u < b ? t + kLead + 1u : b;
+        for (uint32_t i = 1; i < cnt; ++i) order[r0 + F(ahead) + L(t) + (i - 1u)] = pb + i;
+#endif
     }
 }
 

@@ -158,8 +158,7 @@ def test_no_scratch_access_inside_the_hand_counted_load_windows(tmp_path):
     and a fragment is used before it has arrived -- wrong cells, silently.  Round 5 met it twice while editing the kernel
     (an explicit zero C operand: 80 spilled registers; two more scalar kernel arguments: the band kernel).  In every
     instantiation of triangle_mfma_kernel in the shipped code object: no scratch access between the last `vmcnt(0)` in front
-    of a K loop's first MFMA and its last MFMA.  Also: the triangle instantiations start their
-    accumulators through the C operand of the first MFMAs (the inline constant 0), not with 128 VALU moves."""
+    of a K loop's first MFMA and its last MFMA."""
     import shutil
     import subprocess
 
@@ -170,7 +169,7 @@ def test_no_scratch_access_inside_the_hand_counted_load_windows(tmp_path):
         pytest.skip("llvm-objdump not in this image")
     shutil.copy(_lib.LIB_PATH, tmp_path / "libldx.so")
     subprocess.run([str(objdump), "--offloading", "libldx.so"], cwd=tmp_path, capture_output=True, check=True)
-    seen, zero_c = 0, {}
+    seen = 0
     for obj in sorted(tmp_path.glob("libldx.so.*gfx950")):
         text = subprocess.run([str(objdump), "-d", str(obj)], capture_output=True, text=True, check=True).stdout
         funcs, cur = {}, None
@@ -201,10 +200,7 @@ def test_no_scratch_access_inside_the_hand_counted_load_windows(tmp_path):
                 bad = [(k, ins[k]) for k in range(lo, hi + 1) if ins[k].startswith("scratch_")]
                 assert not bad, f"{name[:70]}: scratch access inside a hand-counted window: {bad[:4]}"
                 seen += 1
-            zero_c[name] = sum(1 for k in mf if re.search(r"\], 0(?: |$)", ins[k]))
     assert seen >= 14                                   # every instantiation's K loops were looked at
-    tri_fp4 = [n for n in zero_c if "Lb0ELb1E" in n.split("triangle_mfma_kernelI")[1][:24] and "ILb0ELb0ELb0ELb1E" in n]
-    assert tri_fp4 and all(zero_c[n] >= 12 for n in tri_fp4), {n[:60]: zero_c[n] for n in tri_fp4}   # 8 (64-row unit) + 4 (half-height)
 
 
 def test_geometry_helpers():

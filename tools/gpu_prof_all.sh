@@ -7,12 +7,20 @@
 # then a default `python bench.py` (no profiler) whose line is kept beside them.
 # Usage on the GPU box: bash tools/gpu_prof_all.sh r03      Afterwards, in the build container, right away (the commit must
 # be the one that was sent):  python tools/save_profile_all.py r03
+# Round 5: seven passes per profile (trace, fetch, write, four SQ counter sets) no longer fit one 20-minute visit:
+#   ONLY="a b" bash tools/gpu_prof_all.sh r05      then      ONLY="c d bench" bash tools/gpu_prof_all.sh r05
 set -u
 R=${1:-r03}
+ONLY=${ONLY:-a b c d bench}
 COMMON="--no-cpu-baseline --no-other-workloads"
-bash tools/gpu_prof.sh ${R}a --steps 20 --warmup 3 $COMMON > gpurun_out/prof_all_${R}a.log 2>&1; echo "[${R}a] exit $?"
-bash tools/gpu_prof.sh ${R}b --steps 10 --warmup 2 --snps 40000 --no-extra-legs $COMMON > gpurun_out/prof_all_${R}b.log 2>&1; echo "[${R}b] exit $?"
-bash tools/gpu_prof.sh ${R}c --steps 10 --warmup 2 --snps 50000 --haps 1008 --no-extra-legs $COMMON > gpurun_out/prof_all_${R}c.log 2>&1; echo "[${R}c] exit $?"
-PROG="tools/gpu_exp.py area" bash tools/gpu_prof.sh ${R}d > gpurun_out/prof_all_${R}d.log 2>&1; echo "[${R}d] exit $?"
-timeout -k 10 500 python3 bench.py > gpurun_out/bench_default_${R}.json 2> gpurun_out/bench_default_${R}.err; echo "[bench default] exit $?"
-tail -c 400 gpurun_out/bench_default_${R}.json
+mkdir -p gpurun_out
+for what in $ONLY; do
+  case $what in
+    a) bash tools/gpu_prof.sh ${R}a --steps 20 --warmup 3 $COMMON > gpurun_out/prof_all_${R}a.log 2>&1; echo "[${R}a] exit $?";;
+    b) bash tools/gpu_prof.sh ${R}b --steps 10 --warmup 2 --snps 40000 --no-extra-legs $COMMON > gpurun_out/prof_all_${R}b.log 2>&1; echo "[${R}b] exit $?";;
+    c) bash tools/gpu_prof.sh ${R}c --steps 10 --warmup 2 --snps 50000 --haps 1008 --no-extra-legs $COMMON > gpurun_out/prof_all_${R}c.log 2>&1; echo "[${R}c] exit $?";;
+    d) PROG="tools/gpu_exp.py area" bash tools/gpu_prof.sh ${R}d > gpurun_out/prof_all_${R}d.log 2>&1; echo "[${R}d] exit $?";;
+    bench) timeout -k 10 500 python3 bench.py > gpurun_out/bench_default_${R}.json 2> gpurun_out/bench_default_${R}.err; echo "[bench default] exit $?"
+           tail -c 400 gpurun_out/bench_default_${R}.json;;
+  esac
+done

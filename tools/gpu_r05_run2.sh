@@ -1,4 +1,8 @@
 #!/bin/bash
 set -u
 mkdir -p gpurun_out
-LIBS="libldx_base libldx_r5b libldx libldx_u4 libldx_u16" ROUNDS=3 SHAPES="10000 5008 fp4 200 k16|3000 5008 fp4 400 k16|40000 5008 fp4 10 k16|50000 1008 fp4 10 k16" PMC=1 bash tools/gpu_abx.sh > gpurun_out/abx_unroll.log 2>&1; grep -v "^\[pmc" gpurun_out/abx_unroll.log | tail -80
+LIBS="libldx_ff libldx" CHECK="area" AREA=1 ROUNDS=3 SHAPES="10000 5008 fp4 100 k16" bash tools/gpu_abx.sh
+for v in libldx_ff libldx; do
+  LDX_LIB=$PWD/ld_tools_amd/$v.so PROG="tools/gpu_exp.py area" PASSES="trace fetch write" bash tools/gpu_prof.sh r05d_$v > gpurun_out/prof_band_$v.log 2>&1
+  echo "== $v"; grep -A3 "== traffic" gpurun_out/prof_band_$v.log | tail -2; grep "triangle_mfma_kernel<false, false, true" gpurun_out/prof_band_$v.log | head -3
+done

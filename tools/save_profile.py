@@ -31,6 +31,14 @@ if (src / "command.txt").exists():
     shutil.copy(src / "command.txt", dst / f"{tag}_command.txt")
 if (src / "launch_durations.json").exists():    # per-launch mean / median / min and the steady back-to-back run (prof_summary.py)
     shutil.copy(src / "launch_durations.json", dst / f"{tag}_launch_durations.json")
+# round 5: where the cycles go (tools/pmc_table.py over the sq / sq2 / sq3 / sq4 counter passes)
+tab = subprocess.run([sys.executable, str(root / "tools" / "pmc_table.py"), str(src), "triangle_mfma_kernel"], capture_output=True, text=True)
+if tab.returncode == 0 and tab.stdout.strip():
+    (dst / f"{tag}_cycle_accounting.txt").write_text(tab.stdout)
+    if (src / "pmc_table.json").exists():
+        shutil.copy(src / "pmc_table.json", dst / f"{tag}_counters.json")
+else:
+    print("no cycle table:", tab.stderr.strip()[-300:])
 if (src / "traffic_counters.json").exists():
     rec = json.loads((src / "traffic_counters.json").read_text())
     sys.path.insert(0, str(root))
