@@ -1036,6 +1036,18 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 // LDX_STEP_UNROLL steps per trip of the loop (1, 2, 4, 8 or 16; the rows of a step are (e & 3) + 8 (e >> 2) + 32 m:
                 // unrolled by 4 the row inside its group of eight is static -- LDS and store offsets become immediates, the
                 // scalar address arithmetic happens once per four steps --, unrolled by 16 the accumulator index is static too)
+                auto load_rows = [&](int e, F32Row (&dst)[MM]) {
+#pragma unroll
+                    for (int m = 0; m < MM; ++m) {   // two addresses per wave: broadcast
+                        const v4f v = *reinterpret_cast<const v4f *>(rt + (32u * m + (e & 3) + 8u * (e >> 2)) * 4u);
+                        dst[m] = F32Row{v.x, v.y, v.z, v.w};
+                    }
+                };
+#ifdef LDX_ROW_PREFETCH   // the rows of step e + 1 are read at the top of step e (two buffers; needs an even LDX_STEP_UNROLL)
+                static_assert(LDX_STEP_UNROLL % 2 == 0, "LDX_ROW_PREFETCH alternates two row buffers: unroll by an even number");
+                F32Row rowbuf[2][MM];
+                load_rows(0, rowbuf[0]);
+#endif
 #pragma unroll 1
                 for (int e_ = 0; e_ < 16; e_ += LDX_STEP_UNROLL) {
 #pragma unroll
@@ -1044,12 +1056,13 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
 #if defined(LDX_TUNING) && defined(LDX_STAMPS_ONLY)
                     if (my_stamps && lane == 0 && npass == 1) my_stamps[6 + 4 * kStampPasses + e] = __builtin_amdgcn_s_memtime();
 #endif
+#ifdef LDX_ROW_PREFETCH
+                    F32Row (&rows)[MM] = rowbuf[r_ & 1];
+                    load_rows((e + 1) & 15, rowbuf[(r_ + 1) & 1]);   // (after the last step: step 0's rows again, unused)
+#else
                     F32Row rows[MM];
-#pragma unroll
-                    for (int m = 0; m < MM; ++m) {   // two addresses per wave: broadcast
-                        const v4f v = *reinterpret_cast<const v4f *>(rt + (32u * m + (e & 3) + 8u * (e >> 2)) * 4u);
-                        rows[m] = F32Row{v.x, v.y, v.z, v.w};
-                    }
+                    load_rows(e, rows);
+#endif
                     Cell cell[4 * MM];
                     float wmax = 0.0f, ymin = 1.0f;
 #pragma unroll

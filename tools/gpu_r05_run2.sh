@@ -1,8 +1,5 @@
 #!/bin/bash
 set -u
 mkdir -p gpurun_out
-LIBS="libldx_ff libldx" CHECK="area" AREA=1 ROUNDS=3 SHAPES="10000 5008 fp4 100 k16" bash tools/gpu_abx.sh
-for v in libldx_ff libldx; do
-  LDX_LIB=$PWD/ld_tools_amd/$v.so PROG="tools/gpu_exp.py area" PASSES="trace fetch write" bash tools/gpu_prof.sh r05d_$v > gpurun_out/prof_band_$v.log 2>&1
-  echo "== $v"; grep -A3 "== traffic" gpurun_out/prof_band_$v.log | tail -2; grep "triangle_mfma_kernel<false, false, true" gpurun_out/prof_band_$v.log | head -3
-done
+timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "half_height or triangle_matches_golden or edge_shapes or agree_bitwise or random_shapes or fuzz or sharded_units" > gpurun_out/quart_pytest.log 2>&1; echo "[pytest] $?"; tail -5 gpurun_out/quart_pytest.log
+for n in 10000 8000 6000; do echo "== $n"; timeout -k 10 400 python tools/gpu_short.py $n 5008 200 2>&1 | grep -v amdgpu.ids; done
