@@ -206,6 +206,12 @@ constexpr uint32_t kSchedSlots = 256;
 constexpr uint32_t kCuSlots = 2048;
 constexpr uint32_t kSchedWords = 3u + kCuSlots;   // (the last word is unused since round 5: the finished-launch numbers live in pinned host memory)
 __device__ uint32_t g_sched[kSchedSlots][kSchedWords];
+// ... and one PRIVATE pair of counters per launch recorded under stream capture (round 5): a captured launch is replayed by
+// whoever launches its graph, on any stream, at any time -- nothing ties it to the stream it was captured on, and two graphs
+// captured on one stream (torch captures every graph on the same side stream) may well be replayed at the same time on two.
+// 64 bytes (a cache line) per captured launch, never handed out twice: 65 536 captured launches per process and device.
+constexpr uint32_t kCaptSets = 65536, kCaptWords = 16;
+__device__ uint32_t g_capt[kCaptSets][kCaptWords];
 __device__ unsigned long long g_dbg[8];   // tuning builds (-DLDX_TUNING): event counters, see ldx_debug_counters
 #if defined(LDX_TUNING) && !defined(LDX_STAMPS_ONLY)
 #define LDX_COUNT(slot, v) do { if (lane == 0) atomicAdd(&g_dbg[slot], (unsigned long long)(v)); } while (0)
@@ -1502,12 +1508,13 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
 // which the loader zero-fills; every launch leaves its slot re-armed (the last workgroup out resets the words with
 // agent-scope atomic stores), so a launch costs no memset node.  (ld_area's band keeps its counters in the caller's
 // workspace instead: area_mfma.)
+// Launches recorded under stream capture do not use the slots at all: each gets its own counters (g_capt above), so a
+// graph can be replayed on any stream, beside any other graph or eager launch.
 // Reclaiming (round 4).  A process that keeps creating streams (one per chromosome, per table ...) runs out of the 256
 // slots of a device.  Every launch carries a sequence number (AreaArgs::launch_seq) that its last workgroup publishes
 // when it ends; when no slot is free the host takes a slot whose last ISSUED launch has FINISHED -- whatever became of
-// the stream that owned it (destroyed, idle, reused) -- and that was never used under stream capture (a captured graph
-// has the slot's address baked into its kernel nodes and may be replayed at any time).  The old owner, should it launch
-// again, simply acquires a slot anew.  Only when all 256 slots are in flight or captured does the call fail: kNoSlot,
+// the stream that owned it (destroyed, idle, reused).  The old owner, should it launch again, simply acquires a slot
+// anew.  Only when all 256 slots are in flight (or 65 536 launches have been captured) does the call fail: kNoSlot,
 // which the entry points turn into the popcount kernel for LDX_PATH_AUTO (identical results) and into
 // LDX_E_UNSUPPORTED for an explicit matrix-pipe path.
 // Round 5 (ADVICE r04 + VERDICT r04 item 8):
@@ -1543,14 +1550,15 @@ static int acquire_sched(hipStream_t s, uint32_t **sched, uint32_t *launch_seq, 
         uint32_t issued = 0;       // sequence number of the last launch issued on the slot (monotone across owners)
         bool in_use = false;
         bool owned = false;        // `owner` still maps to this slot (false: an orphan waiting for its launch to end)
-        bool captured = false;     // a launch was recorded into a graph: never reclaimed
     };
     struct PerDevice {
         uint32_t (*pool)[kSchedWords] = nullptr;   // this device's g_sched
         Slot slots[kSchedSlots];
         uint32_t next_slot = 0;                    // slots handed out for the first time so far
-        uint32_t *done = nullptr;                  // [kSchedSlots] pinned host memory: number of the last FINISHED launch
-        uint32_t *done_dev = nullptr;              // ... as the device addresses it
+        uint32_t *done = nullptr;                  // [kSchedSlots + 1] pinned host memory: number of the last FINISHED launch
+        uint32_t *done_dev = nullptr;              // ... as the device addresses it (the last word: where captured launches write)
+        uint32_t (*capt)[kCaptWords] = nullptr;    // this device's g_capt
+        uint32_t next_capt = 0;                    // private counter sets handed to captured launches so far
     };
     static std::mutex sched_mutex;
     static std::unordered_map<Key, uint32_t, KeyHash> sched_slot;
@@ -1570,8 +1578,11 @@ static int acquire_sched(hipStream_t s, uint32_t **sched, uint32_t *launch_seq, 
         void *sym = nullptr;
         LDX_HIP(hipGetSymbolAddress(&sym, HIP_SYMBOL(g_sched)));   // the current device's copy of the symbol
         void *host = nullptr, *devp = nullptr;
-        LDX_HIP(hipHostMalloc(&host, kSchedSlots * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
-        memset(host, 0, kSchedSlots * sizeof(uint32_t));
+        void *csym = nullptr;
+        LDX_HIP(hipGetSymbolAddress(&csym, HIP_SYMBOL(g_capt)));
+        pd.capt = reinterpret_cast<uint32_t (*)[kCaptWords]>(csym);
+        LDX_HIP(hipHostMalloc(&host, (kSchedSlots + 1u) * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
+        memset(host, 0, (kSchedSlots + 1u) * sizeof(uint32_t));
         LDX_HIP(hipHostGetDevicePointer(&devp, host, 0));
         pd.done = (uint32_t *)host;
         pd.done_dev = (uint32_t *)devp;
@@ -1580,6 +1591,19 @@ static int acquire_sched(hipStream_t s, uint32_t **sched, uint32_t *launch_seq, 
     auto finished = [&](uint32_t k) {   // the slot's last issued launch has ended (acquire: its re-arming stores came first)
         return __atomic_load_n(&pd.done[k], __ATOMIC_ACQUIRE) == pd.slots[k].issued;
     };
+    if (cap != hipStreamCaptureStatusNone) {   // a recorded launch: its own counters, nothing shared with any stream
+#ifndef LDX_TUNING   // (tuning builds keep the slots: their K-loop token lives behind the counters)
+        if (pd.next_capt >= kCaptSets) {
+            set_error("ld_triangle on the matrix pipe: %u launches have been recorded under stream capture on device %d; no "
+                      "private ticket counters are left", kCaptSets, dev);
+            return kNoSlot;
+        }
+        *sched = pd.capt[pd.next_capt++];
+        *launch_seq = 1u;
+        *done_host = pd.done_dev + kSchedSlots;   // (nobody reads it)
+        return LDX_OK;
+#endif
+    }
     const Key key{dev, s};
     const auto now = std::chrono::steady_clock::now();
     uint32_t slot = 0;
@@ -1589,8 +1613,7 @@ static int acquire_sched(hipStream_t s, uint32_t **sched, uint32_t *launch_seq, 
         slot = it->second;
         have = true;
         Slot &c = pd.slots[slot];
-        if (cap == hipStreamCaptureStatusNone && !c.captured && !finished(slot) &&
-            now - c.last > std::chrono::microseconds(50)) {
+        if (cap == hipStreamCaptureStatusNone && !finished(slot) && now - c.last > std::chrono::microseconds(50)) {
             const hipError_t q = hipStreamQuery(s);
             if (q != hipSuccess) (void)hipGetLastError();   // hipErrorNotReady: the launch is the caller's own, still running
             if (q == hipSuccess && !finished(slot)) {        // idle stream, unfinished launch: a recycled handle
@@ -1607,15 +1630,14 @@ static int acquire_sched(hipStream_t s, uint32_t **sched, uint32_t *launch_seq, 
             bool found = false;
             for (uint32_t k = 0; k < kSchedSlots && !found; ++k) {
                 const Slot &c = pd.slots[k];
-                if (c.in_use && !c.captured && finished(k)) {
+                if (c.in_use && finished(k)) {
                     if (c.owned) sched_slot.erase(Key{dev, c.owner});
                     slot = k;
                     found = true;
                 }
             }
             if (!found) {
-                set_error("ld_triangle on the matrix pipe: all %u ticket-counter slots of device %d are in flight or "
-                          "belong to captured graphs", kSchedSlots, dev);
+                set_error("ld_triangle on the matrix pipe: all %u ticket-counter slots of device %d are in flight", kSchedSlots, dev);
                 return kNoSlot;
             }
         }
@@ -1628,7 +1650,6 @@ static int acquire_sched(hipStream_t s, uint32_t **sched, uint32_t *launch_seq, 
         sched_slot.emplace(key, slot);
     }
     Slot &mine = pd.slots[slot];
-    if (cap != hipStreamCaptureStatusNone) mine.captured = true;
     mine.last = now;
     if (++mine.issued == 0u) mine.issued = 1u;   // (0 is what a never-used slot's host word says)
     *launch_seq = mine.issued;

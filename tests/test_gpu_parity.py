@@ -851,6 +851,52 @@ def test_graph_of_launches_into_alternating_buffers(gpu):
                 assert torch.equal(o.cells, ref.cells), (rnd, name, k)
 
 
+def test_two_triangle_graphs_of_one_capture_stream_replayed_at_once(gpu):
+    """A launch recorded under stream capture gets its own ticket counters (round 5; csrc/ldx_mfma.hip, g_capt): torch captures
+    every graph on one and the same side stream, so two graphs -- two panels here, several launches each -- used to carry
+    the counters of that stream's slot, and replayed at the same time on two streams they would have shared them.  Two
+    threads replay one graph each, on their own streams, fifty times; every result buffer equals the eager result."""
+    import threading
+
+    import torch
+    from ld_tools_amd import PackedPanel, ld_triangle, synth
+
+    jobs = []
+    for n, seed in ((6000, 21), (7000, 22)):                     # more passes than the 512 static tickets: the counters are in use
+        p = PackedPanel.from_codes(synth.synth_codes_device(n, 1008, seed=seed))
+        ref = ld_triangle(p, fmt="k16")
+        outs = [ld_triangle(p, fmt="k16") for _ in range(2)]
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for k in range(4):
+                ld_triangle(p, out=outs[k & 1], fmt="k16")
+        jobs.append((g, outs, ref))
+    errors = []
+
+    def worker(g, outs, ref):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for rep in range(50):
+                    for o in outs:
+                        o.cells.fill_(-1)
+                    g.replay()
+                    st.synchronize()
+                    if not all(torch.equal(o.cells, ref.cells) for o in outs):
+                        errors.append(rep)
+                        return
+        except Exception as exc:   # noqa: BLE001
+            errors.append(repr(exc))
+
+    threads = [threading.Thread(target=worker, args=j) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
 def test_area_plans_replayed_on_two_streams_at_once(gpu):
     """every ld_area plan graph used to carry the ticket-counter slot of torch's one capture stream, so two plans
     replayed at the same time on two streams shared their counters.  The band's counters now live in the plan's own
