@@ -1,4 +1,11 @@
 #!/usr/bin/env python3
+"""The sequence that showed round 5's bug: V=0 python tools/gpu_streams_dbg.py
+
+A one-stream HIP graph of ld_triangle launches into ALTERNATING result buffers, captured BEFORE two side streams are used
+eagerly and a fork / join graph is captured (V=0, V=3); then replayed.  With the ticket counters re-armed by plain stores
+every launch of the one-stream graph after its first drew no ticket beyond its static one (results equal: [True, False]
+at half the time).  V=1 captures the graphs in the other order, V=2 only the one-stream graph: both were always right.
+Now a GPU test (test_graph_of_launches_into_alternating_buffers)."""
 import os
 import sys
 from pathlib import Path
