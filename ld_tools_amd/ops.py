@@ -415,7 +415,8 @@ def ld_area(panel: PackedPanel, positions, queries: Optional[Sequence[int]] = No
         if key is not None and plan.graph is None and (use_graph or plan.uses >= 2) and \
                 not torch.cuda.is_current_stream_capturing():
             try:                                    # capture the launches once; a failure leaves the eager path
-                torch.cuda.current_stream().synchronize()   # this stream only: table workers on other streams keep running
+                torch.cuda.current_stream().synchronize()   # this stream's launches are done (torch's graph context then
+                                                            # synchronises the device once more, on every capture: its own rule)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):   # other threads (the shells' table workers) keep allocating
                     _area_launch(panel, pos, q, nq, flank, measure, thres, plan)
