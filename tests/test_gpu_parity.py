@@ -1106,9 +1106,9 @@ def test_config3_triangle_100k_all_eight_shards(gpu):
     """BASELINE configs[3] at FULL size on one card: 100 000 SNPs x 5008 haplotypes, all eight unit ranges of
     dist.unit_partition(100000, 8) one after the other (4 B cells + counts: 5 GB per shard, 5.0e9 pairs in all) -- what the
     eight ranks compute, minus the RCCL hop (tests/test_gpu_dist.py, tests/test_dist_gloo.py).  Per shard: the FP4 kernel
-    and the popcount kernel agree on every cell and every count, the int8 kernel agrees on a sub-range of units, and rows
-    that fall into the shard match the C oracle; over the eight shards every unit is covered once and the n11 mass of
-    the whole triangle equals sum_h C(k_h, 2)."""
+    and the popcount kernel agree on every cell and every count, the int8 kernel agrees on a sub-range of units, and 1 % of
+    the rows -- all their cells, 5.0e7 -- match the C oracle; over the eight shards every unit is covered once and the n11
+    mass of the whole triangle equals sum_h C(k_h, 2)."""
     import torch
     from ld_tools_amd import dist, ld_triangle, synth
     from ld_tools_amd._lib import UNIT_PAIRS, cell_offset
@@ -1122,7 +1122,11 @@ def test_config3_triangle_100k_all_eight_shards(gpu):
     o = c_oracle.Panel(codes)
     npad = ((n + 127) // 128) * 128
     G = npad // 8
-    rows_to_check = (130, 20011, 38000, 52001, 61007, 70001, 84444, 93000, 99999)
+    # 1 % of the rows, ALL their cells (5.0e7 of the 5.0e9), against the oracle -- every 100th row plus a few odd ones
+    # (nine rows before) -- each row cut into the pieces that fall into the eight unit ranges
+    from concurrent.futures import ThreadPoolExecutor
+
+    rows_to_check = sorted(set(range(37, n, 100)) | {130, 20011, 38000, 52001, 61007, 70001, 84444, 93000, 99999})
     mass, checked, shards_checked = 0, 0, set()
     for r, (u0, u1) in enumerate(parts):
         a = ld_triangle(p, unit_range=(u0, u1), want_n11=True, fmt="k16", path="fp4")
@@ -1140,6 +1144,7 @@ def test_config3_triangle_100k_all_eight_shards(gpu):
         assert torch.equal(c.k16, a.k16[lo: lo + 4000 * UNIT_PAIRS]), f"shard {r}: int8 kernel"
         del c
         mass += int(a.n11.to(torch.int64).sum().item())
+        pieces, idx_all = [], []
         for row in rows_to_check:
             cols = np.arange(row, dtype=np.int64)
             t_ = cols // 128
@@ -1149,23 +1154,36 @@ def test_config3_triangle_100k_all_eight_shards(gpu):
                 continue
             cm = cols[m]
             assert np.array_equal(cm, np.arange(cm[0], cm[-1] + 1))               # a row's units inside a range are contiguous
-            idx = torch.from_numpy((u[m] - u0) * UNIT_PAIRS + cell_offset(row % 8, cm % 128, "k16")).to(a.k16.device)
-            want_n = o.pair_counts(row, row + 1, int(cm[0]), int(cm[-1]) + 1)[0]
-            k = len(cm)
-            _, _, w_rsq, w_dp, w_flags = c_oracle.ld_from_counts_v(
-                h, want_n, np.full(k, o.acnt[row], np.uint32), np.full(k, o.rcnt[row], np.uint32), o.acnt[cm], o.rcnt[cm],
-                libm_pow=True)                                                    # var_1 = row, var_2 = column
-            assert np.array_equal(a.n11[idx].cpu().numpy().view(np.uint32), want_n)
-            cells = a.k16[idx].cpu().numpy().astype(np.int64) & 0xFFFF
-            int0 = np.stack([(w_flags & 2) != 0, (w_flags & 1) != 0], axis=1)
-            want_k = np.stack([np.rint(w_rsq * 1e4), np.rint(w_dp * 1e4)], axis=1).astype(np.int64)
-            assert np.array_equal(cells, np.where(int0, 0x8000, want_k)), (r, row)
-            checked += k
+            idx_all.append((u[m] - u0) * UNIT_PAIRS + cell_offset(row % 8, cm % 128, "k16"))
+            pieces.append((row, int(cm[0]), int(cm[-1]) + 1))
+        if pieces:
+            idx = torch.from_numpy(np.concatenate(idx_all)).to(a.k16.device)      # one gather per shard
+            got_n = a.n11[idx].cpu().numpy().view(np.uint32)
+            got_c = a.k16[idx].cpu().numpy().astype(np.int64) & 0xFFFF
+            offs = np.concatenate([[0], np.cumsum([c1 - c0 for _, c0, c1 in pieces])])
+
+            def one(k):
+                row, c0, c1 = pieces[k]
+                want_n = o.pair_counts(row, row + 1, c0, c1)[0]
+                m_ = c1 - c0
+                cm = np.arange(c0, c1)
+                _, _, w_rsq, w_dp, w_flags = c_oracle.ld_from_counts_v(
+                    h, want_n, np.full(m_, o.acnt[row], np.uint32), np.full(m_, o.rcnt[row], np.uint32), o.acnt[cm], o.rcnt[cm],
+                    libm_pow=True)                                                # var_1 = row, var_2 = column
+                sl = slice(offs[k], offs[k + 1])
+                assert np.array_equal(got_n[sl], want_n), (r, row, "n11")
+                int0 = np.stack([(w_flags & 2) != 0, (w_flags & 1) != 0], axis=1)
+                want_k = np.stack([np.rint(w_rsq * 1e4), np.rint(w_dp * 1e4)], axis=1).astype(np.int64)
+                assert np.array_equal(got_c[sl], np.where(int0, 0x8000, want_k)), (r, row)
+                return m_
+
+            with ThreadPoolExecutor(max_workers=8) as pool:
+                checked += sum(pool.map(one, range(len(pieces))))
             shards_checked.add(r)
         del a
         torch.cuda.empty_cache()
     assert parts[-1][1] * UNIT_PAIRS >= n * (n - 1) // 2
-    assert checked > 400000 and len(shards_checked) >= 5
+    assert checked == sum(rows_to_check) and len(shards_checked) == 8      # every cell of those rows, in every shard
     colsum = (codes_d == 1).sum(dim=0, dtype=torch.int64)
     assert mass == int((colsum * (colsum - 1) // 2).sum().item())
 
