@@ -708,6 +708,9 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
             block_sync();
             LDX_STAMP(1);
             if (ablate & 32) __builtin_amdgcn_s_setprio(2);   // tuning: the K-loop wave outranks the epilogue wave instead
+#if defined(LDX_AB_BANDPRIO)   // tuning: in the band (both waves of a SIMD in their K loops most of the time) one workgroup of the CU outranks the other
+            if (kArea) { if (LDX_AB_BANDPRIO == 1 ? (blockIdx.x >= gridDim.x / 2u) : (blockIdx.x & 1u)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+#endif
             v4i af0[MM], bf0[4], af1[MM], bf1[4];
             read_bf(bf0, bexp, 0);
 #pragma unroll
