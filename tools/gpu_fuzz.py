@@ -8,7 +8,9 @@ all-missing rows), packs it, and compares
   * ld_triangle: 'fp4' and 'mfma' against 'popcount', both cell formats, with and without the n11 plane, on the whole
     triangle and on a random unit range, each matrix-pipe launch repeated (the second launch into a poisoned buffer);
   * ld_pairs, pair_counts and the fused drop-in calc_ld on random pairs against the triangle's cells and n11 plane;
-  * ld_area: the three kernels' ordered hit lists for a random flank / measure / threshold / query subset.
+  * ld_area: the three kernels' ordered hit lists for a random flank / measure / threshold / query subset;
+  * (one round in twenty) a HIP graph of two to five matrix-kernel launches into two alternating result buffers, some of
+    them forked onto a side stream, replayed twice.
 Any difference is printed with its shape and seed and the process exits 1.  The popcount kernels are the independent
 second implementation (they share no counting or staging code with the matrix-pipe kernel) and are themselves pinned to
 the oracle and the reference's golden outputs by tests/test_gpu_parity.py.
@@ -34,7 +36,7 @@ def run(budget: float = 120.0, seed: int = 1, progress: float = 0.0) -> str:
     rng = np.random.RandomState(seed)
     t_end = time.time() + budget
     t_say = time.time() + progress
-    rounds = pairs = hits = 0
+    rounds = pairs = hits = graphs = 0
 
     def fail(msg):
         raise Mismatch(msg)
@@ -69,6 +71,37 @@ def run(budget: float = 120.0, seed: int = 1, progress: float = 0.0) -> str:
                     got.cells.view(view).fill_(-1)
                     ld_triangle(p, fmt=fmt, path=path, want_n11=want_n11, unit_range=ur, out=got)
             pairs += ref.cells.shape[0]
+        # launches chained by a HIP graph instead of a stream (round 5: such launches, into alternating result buffers, lost
+        # their tickets): a few launches of either matrix kernel, sometimes forked onto a side stream, replayed twice
+        if graphs < 2000 and rng.rand() < 0.05:
+            gfmt = str(rng.choice(["k16", "ld32"]))
+            gview = torch.int16 if gfmt == "k16" else torch.int32
+            gref = ld_triangle(p, fmt=gfmt, path="popcount")
+            bufs = [ld_triangle(p, fmt=gfmt, path="fp4"), ld_triangle(p, fmt=gfmt, path="fp4")]
+            plan = [(str(rng.choice(["fp4", "mfma"])), int(k & 1), bool(rng.rand() < 0.3)) for k in range(int(rng.randint(2, 6)))]
+            side = torch.cuda.Stream()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                cur = torch.cuda.current_stream()
+                for gpath, b, fork in plan:
+                    if fork:
+                        side.wait_stream(cur)
+                        with torch.cuda.stream(side):
+                            ld_triangle(p, fmt=gfmt, path=gpath, out=bufs[b])
+                        cur.wait_stream(side)
+                    else:
+                        ld_triangle(p, fmt=gfmt, path=gpath, out=bufs[b])
+            for rep in range(2):
+                for o in bufs:
+                    o.cells.view(gview).fill_(-1)
+                g.replay()
+                torch.cuda.synchronize()
+                for b in sorted({b for _, b, _ in plan}):
+                    if not torch.equal(bufs[b].cells.view(gview), gref.cells.view(gview)):
+                        fail(f"HIP graph of launches {plan} {gfmt}, buffer {b}, replay {rep}: {tag}")
+            graphs += 1
+            del g, bufs, gref
         # the other entry points on the same panel: explicit pair list, rectangular counts, the fused drop-in
         m = max(1, min(64, n * (n - 1) // 2))
         rr = rng.randint(1, n, size=m)
@@ -119,7 +152,7 @@ def run(budget: float = 120.0, seed: int = 1, progress: float = 0.0) -> str:
             print(f"  ... {rounds} panels, no difference", flush=True)
             t_say = time.time() + progress
     return (f"fuzz ok: {rounds} panels, {pairs} triangle cells x 2 kernels x 2 launches, {hits} ld_area hits x 2 kernels, "
-            f"{budget:.0f} s")
+            f"{graphs} HIP graphs of launches, {budget:.0f} s")
 
 
 if __name__ == "__main__":
