@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define LDX_VERSION 101            /* 0.1.1: cell order inside a unit, ldx_triangle_cell_index takes the format */
+#define LDX_VERSION 102            /* 0.1.2: ldx_triangle_ex_dev takes the pass scheduler's workspace (the library keeps no per-stream state) */
 #define LDX_SLAB_ROWS 128u         /* SNP rows per slab == SNP columns per j-tile */
 #define LDX_GROUP_ROWS 8u          /* SNP rows a wavefront pairs against one j-tile per unit */
 #define LDX_CHUNK_HAPS 128u        /* haplotypes per 16-byte chunk */
@@ -193,10 +193,25 @@ int ldx_triangle_dev(const void *alt, const double *fa, const double *fr, const 
 int ldx_set_triangle_path(int path);
 int ldx_get_triangle_path(void);
 /* ldx_triangle_dev with the kernel path and the cell format per call.  out: ldx_ld32 or ldx_k16 cells
- * (out_format = LDX_OUT_LD32 / LDX_OUT_K16), indexed as in ldx_triangle_dev.  out_raw needs LDX_OUT_LD32. */
+ * (out_format = LDX_OUT_LD32 / LDX_OUT_K16), indexed as in ldx_triangle_dev.  out_raw needs LDX_OUT_LD32.
+ * workspace (ABI 102): ldx_triangle_workspace_bytes() bytes of device memory, 256-byte aligned, that hold the matrix
+ * kernel's pass scheduler (two ticket counters).  Contract:
+ *   - ZERO it once before the first launch that uses it (hipMemsetAsync, torch.zeros, or ldx_triangle_workspace_init_dev);
+ *     every launch leaves it zeroed again -- re-armed by its last workgroup -- so it is never touched by the host afterwards;
+ *   - ONE workspace per launch that may be in flight: launches that may overlap (different streams, parallel branches of a
+ *     graph, two graphs replayed at once) need different workspaces; consecutive launches of one stream, or consecutive
+ *     nodes of one graph, may share one.  ld_tools_amd.ld_triangle keeps one per result buffer (TriangleResult.ws);
+ *   - the library keeps NO scheduling state of its own (no per-stream slots, no limit on streams or captured launches, no
+ *     allocation, nothing to leak); a launch recorded under stream capture is like any other;
+ *   - workspace = NULL is allowed: the passes are then dealt round-robin instead of drawn from the counter (identical
+ *     cells; measured slower on panels of more than one round of passes) -- what ldx_triangle_dev does.
+ * The popcount path ignores the workspace. */
+size_t ldx_triangle_workspace_bytes(void);
+int ldx_triangle_workspace_init_dev(void *workspace, size_t workspace_bytes, void *stream);   /* = hipMemsetAsync(workspace, 0, ...) */
 int ldx_triangle_ex_dev(const void *alt, const double *fa, const double *fr, const double *q,
                         uint32_t n_snps, uint32_t n_hap, uint64_t unit_begin, uint64_t unit_end,
-                        int path, int out_format, void *out, ldx_ld64 *out_raw, uint32_t *out_n11, void *stream);
+                        int path, int out_format, void *out, ldx_ld64 *out_raw, uint32_t *out_n11,
+                        void *workspace, size_t workspace_bytes, void *stream);
 
 /* Strip output -> dense row-major float32 [n_rows][ld] matrix of one measure with the
  * ld_two_dim semantics of ld_triangle.py:114,223-230: cell = rounded measure, or 0 when

@@ -107,7 +107,9 @@ SIGNATURES = {
     "ldx_pair_counts_dev": (_int, [_vp, _u32, _vp, _u32, _u32, _vp, _sz, _vp]),
     "ldx_ld_from_counts_dev": (_int, [_u32, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ldx_triangle_dev": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u64, _u64, _vp, _vp, _vp, _vp]),
-    "ldx_triangle_ex_dev": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u64, _u64, _int, _int, _vp, _vp, _vp, _vp]),
+    "ldx_triangle_ex_dev": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u64, _u64, _int, _int, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ldx_triangle_workspace_bytes": (_sz, []),
+    "ldx_triangle_workspace_init_dev": (_int, [_vp, _sz, _vp]),
     "ldx_triangle_dense_ex_dev": (_int, [_vp, _int, _u32, _int, _int, _dbl, _u32, _u32, _vp, _sz, _vp]),
     "ldx_ld_from_counts_ex_dev": (_int, [_u32, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ldx_ld_pairs_dev": (_int, [_vp, _vp, _vp, _u32, _u32, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),

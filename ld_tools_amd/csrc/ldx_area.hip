@@ -653,9 +653,9 @@ extern "C" int ldx_area_scan_dev(const void *alt, const double *fa, const double
         (path == LDX_PATH_AUTO && (uint64_t)n_query * 16u >= n_snps && n_snps >= 2)) {
         const int rc = area_mfma(alt, fa, fr, q, n_snps, n_hap, positions, queries, n_query, flank, measure, thres, hits, hit_cap,
                                  n_hits, query_counts, workspace, path != LDX_PATH_MFMA, s);
-        if (rc != ldx::kNoSlot) return rc;
+        if (rc != ldx::kNoMatrixPath) return rc;
         if (path != LDX_PATH_AUTO) return LDX_E_UNSUPPORTED;
-        // AUTO and no ticket-counter slot for this stream: the popcount scan below finds the very same hits
+        // AUTO and a bit plane of 4 GiB or more: the popcount scan below finds the very same hits
     }
     const uint32_t qpad = ldx_padded_snps(n_query), T = ldx::n_slabs(n_snps), nch = ldx::n_chunks(n_hap);
     LDX_HIP(hipMemsetAsync(n_hits, 0, sizeof(uint64_t), s));

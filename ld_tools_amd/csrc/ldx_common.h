@@ -48,15 +48,17 @@ __device__ __forceinline__ void store_agent(T *p, T v)
 // ld_triangle.py:224) becomes the exact integer test k >= thres_to_k(thres).
 double thres_to_k(double thres);
 
-// internal return code of the two matrix-pipe entries below: no ticket-counter slot could be had for the stream (all 256 of
-// the device in flight or captured).  LDX_PATH_AUTO callers fall back to the popcount kernels, explicit paths report
-// LDX_E_UNSUPPORTED (the message is set).
-constexpr int kNoSlot = -1000;
+// internal return code of the two matrix-pipe entries below: the matrix kernel cannot take this panel (a bit plane of 4 GiB
+// or more: its K loop addresses the plane with 32-bit lane offsets).  LDX_PATH_AUTO callers fall back to the popcount
+// kernels (identical results), explicit paths report LDX_E_UNSUPPORTED (the message is set).
+constexpr int kNoMatrixPath = -1000;
 
-// ld_triangle on the matrix cores (ldx_mfma.hip); same contract as ldx_triangle_dev after argument checks
+// ld_triangle on the matrix cores (ldx_mfma.hip); same contract as ldx_triangle_ex_dev after argument checks.
+// workspace: triangle_mfma_workspace_bytes() zeroed bytes holding the pass scheduler's ticket counters, or null (round-robin)
+size_t triangle_mfma_workspace_bytes();
 int triangle_mfma(const void *alt, const double *fa, const double *fr, const double *q, uint32_t n_snps, uint32_t n_hap,
                   uint64_t unit_begin, uint64_t unit_end, int out_format, void *out, ldx_ld64 *out_raw, uint32_t *out_n11,
-                  bool fp4, hipStream_t s);
+                  bool fp4, void *workspace, hipStream_t s);
 
 // ld_area on the matrix pipe (ldx_mfma.hip): all (query, opposing) pairs inside the +-flank band through the MFMA
 // kernel; same hit contract as the popcount scan of ldx_area.hip

@@ -1,42 +1,34 @@
-// ld_triangle on the matrix cores: n11 = G . G^T with int8 operands (v_mfma_i32_32x32x32_i8), fused with the
-// count-domain fp64 epilogue (ldx_common.h).  calc_ld.py:30-97 for 8192 pairs per wave unit.
-//
-// Why: AND + BCNT run at 64 lanes/clk/CU (no packed form), i.e. 16 haplotype-pairs per lane-instruction;
-// the int8 MFMA does 1024 MACs/clk/SIMD -- 4x the VALU ceiling -- so the count moves to the matrix pipe
-// and the VALU is left with expanding bits to bytes and with the epilogue.
-//
-// Structure
-//   * 256-thread workgroups (4 waves), two per CU (<= 256 VGPRs, ~48 KiB LDS each): one wave per SIMD and
-//     workgroup, so the partner on a SIMD belongs to the OTHER workgroup -- one runs its VALU epilogue while
-//     the other feeds the matrix pipe.
-//   * a wave's unit is 64 i-rows x 128 j-rows: 2 x 4 accumulator tiles of 32x32 (128 VGPRs); a PASS is four
-//     consecutive units of one j-tile, one per wave; passes are handed out by a ticket counter in global
-//     memory (dynamic: workgroups do not run at the same speed).
-//   * B side (the 128 j-rows, shared by the 4 waves): per 128-haplotype chunk the workgroup expands the
-//     j-tile's bits to bytes ONCE (each lane: 64 bits -> 4 x ds_write_b128, one per K-step) into a
-//     double-buffered LDS image [128 rows][144 B] (rows padded by 16 B: a 16-lane group of ds_read_b128 then
-//     hits 16 distinct 16-byte slots); one LDS-only barrier per chunk.  Fragments are plain ds_read_b128.
-//   * A side (a wave's own 64 rows): each lane loads the 16-byte chunk of "its" row (row = lane % 32 of
-//     each 32-row tile; 32 consecutive rows of a chunk are 512 contiguous bytes) three chunks ahead with
-//     hand-issued global loads (hand-counted s_waitcnt vmcnt), and expands 16 bits per K-step in registers.
-//   * Operand values: hap bit i of a nibble becomes the byte 1 << i on the A side (v_perm_b32 byte replicate
-//     + AND) and 8 >> i on the B side (multiply-spread), slot for slot, so every co-occurrence adds 8: the
-//     accumulators hold 8 * n11.  Row/column placement follows the documented 32x32 C/D map
-//     (col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)); tests compare every cell with
-//     the popcount kernel and the oracle.
-//   * Epilogue: per-SNP operands (counts and reciprocals) staged in LDS per pass / per tile; two pairs at a
-//     time through ld_multi_fast2; a "clean" variant for interior units of ordinary SNPs; pairs that are not
-//     provably rounded like the reference go through the op-for-op mirror.
-// DESIGN.md section 3.1 has the measurements behind each of these choices.
+// ld_triangle / ld_area on the matrix cores: n11 = G . G^T fused with the LD epilogue (calc_ld.py:30-97 for 8192 pairs per
+// wave unit).  One kernel template, triangle_mfma_kernel, in two counting forms:
+//   * kFp4 = true (the default path): v_mfma_f32_32x32x64_f8f6f4 with FP4 (E2M1) operands.  A haplotype bit becomes the
+//     nibble of its own 4-bit group with one AND per eight haplotypes (expand32_a4 / expand32_b4): the A operand keeps the bit
+//     at position p of the nibble, the B operand at 2 - p, every co-occurrence multiplies to exactly 1 and the fp32
+//     accumulators hold n11 exactly (< 2^24).  64 haplotypes per 32 cycles and SIMD: twice the int8 rate.
+//   * kFp4 = false (LDX_PATH_MFMA, the comparison path): v_mfma_i32_32x32x32_i8, bits expanded to bytes; accumulators hold
+//     8 * n11.
+// Structure (both forms)
+//   * 256-thread workgroups (4 waves), two per CU (<= 256 VGPRs each): the partner of a wave on its SIMD belongs to the
+//     OTHER workgroup -- one runs its VALU epilogue while the other feeds the matrix pipe.
+//   * a wave's unit is 64 i-rows x 128 j-rows: 2 x 4 accumulator tiles of 32x32 (128 VGPRs); a PASS is four consecutive
+//     units of one j-tile, one per wave; passes are handed out by a ticket counter (dynamic: workgroups do not run at the
+//     same speed) that lives in the CALLER's workspace (ldx_triangle_workspace_bytes; the band: ldx_area_workspace_bytes)
+//     -- the library keeps no per-stream or per-process scheduling state (round 6).
+//   * B side (the 128 j-rows, shared by the 4 waves): per K-block (256 haplotypes, FP4; 128, int8) the workgroup expands
+//     the j-tile's bits ONCE into an LDS image (double-buffered for the triangle, triple-buffered for the ld_area band);
+//     one LDS-only barrier per K-block.  Fragments are plain ds_read_b128.
+//   * A side (a wave's own 64 rows): each lane loads the 16 bytes of "its" row per K-block (row = lane % 32 of each 32-row
+//     tile, lane half = chunk of the K-block) three blocks ahead with hand-issued global loads (hand-counted s_waitcnt
+//     vmcnt) and expands them in registers.
+//   * Row / column placement follows the documented 32x32 C/D map (col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) +
+//     4 * (lane >> 5)); tests compare every cell with the popcount kernel and the oracle.
+//   * Epilogue tiers (ldx_common.h): fp32 (FP4 triangle, units inside the triangle) -> fp64 count-domain -> op-for-op
+//     mirror; the band screens in fp32, prefilters in fp64 and evaluates queued candidates one pair per lane.
+// DESIGN.md section 3 describes the kernels as they are; HISTORY.md has the measurements behind each choice.
 #include <stdlib.h>
 #include <string.h>
 
 #include <atomic>
-#include <chrono>
-#include <functional>
-#include <mutex>
 #include <type_traits>
-#include <unordered_map>
 
 #include "ldx_common.h"
 #include "ldx_tile.h"
@@ -194,24 +186,18 @@ __host__ __device__ inline uint32_t mfma_pass_base(uint32_t t, uint32_t n_slabs)
     return c(n_slabs) - c(n_slabs - t);
 }
 
-// ticket counters of the dynamic pass scheduler: {next ticket, workgroups finished}; one pair per stream (host side:
-// acquire_sched), zero when the module is loaded and re-armed by the last workgroup out of every launch
-constexpr uint32_t kSchedSlots = 256;
-// ... followed by one K-loop token per physical CU (indexed by XCC / SE / SH / CU id).  The two workgroups of a CU share
-// each SIMD's matrix pipe, and a workgroup's four waves are tied together by its per-K-block barrier, so whenever the two
-// are in their K loops at the same time BOTH run at half speed on all four SIMDs -- and left alone that is most of the
-// time (a wave's partner is in its K loop about half the time, independently per SIMD).  The token lets one workgroup
-// per CU into its K loop at a time; the other is in its epilogue (VALU) or waits.  While the epilogue is not shorter
-// than the K loop nobody waits and each K loop has the matrix pipe to itself.
+// Ticket counters of the dynamic pass scheduler: {next ticket, workgroups finished} at words 0 and 1 of the CALLER's
+// workspace (ldx_triangle_workspace_bytes(); zeroed once by the caller, re-armed by the last workgroup out of every launch
+// with agent-scope stores), so launches that may overlap simply use different workspaces and the library keeps no
+// scheduling state of its own.  Round 6: rounds 1-5 kept a pool of 256 slots per device keyed by
+// (device, hipStream_t) plus 65 536 private sets for captured launches, guarded by sequence numbers in pinned host memory,
+// hipStreamQuery and a 50-us rule against recycled stream handles -- all gone.  Without a workspace (NULL) the passes are
+// dealt round-robin (workgroup b takes tickets b, b + grid, ...): no counter at all, identical cells.
+// Tuning builds only: behind the counters one K-loop token per physical CU (indexed by XCC / SE / SH / CU id).  The token
+// lets one workgroup per CU into its K loop at a time; measured effect on the wall clock: none (HISTORY.md, round 2).
 constexpr uint32_t kCuSlots = 2048;
-constexpr uint32_t kSchedWords = 3u + kCuSlots;   // (the last word is unused since round 5: the finished-launch numbers live in pinned host memory)
-__device__ uint32_t g_sched[kSchedSlots][kSchedWords];
-// ... and one PRIVATE pair of counters per launch recorded under stream capture (round 5): a captured launch is replayed by
-// whoever launches its graph, on any stream, at any time -- nothing ties it to the stream it was captured on, and two graphs
-// captured on one stream (torch captures every graph on the same side stream) may well be replayed at the same time on two.
-// 64 bytes (a cache line) per captured launch, never handed out twice: 65 536 captured launches per process and device.
-constexpr uint32_t kCaptSets = 65536, kCaptWords = 16;
-__device__ uint32_t g_capt[kCaptSets][kCaptWords];
+constexpr uint32_t kSchedWords = 3u + kCuSlots;
+constexpr size_t kTriWorkspaceBytes = (kSchedWords * 4u + 255u) / 256u * 256u;
 __device__ unsigned long long g_dbg[8];   // tuning builds (-DLDX_TUNING): event counters, see ldx_debug_counters
 #if defined(LDX_TUNING) && !defined(LDX_STAMPS_ONLY)
 #define LDX_COUNT(slot, v) do { if (lane == 0) atomicAdd(&g_dbg[slot], (unsigned long long)(v)); } while (0)
@@ -233,17 +219,11 @@ struct AreaArgs {
     const uint32_t *order;         // [passes] ticket -> pass (area_band_plan_kernel: per XCD range the tiles' FIRST passes first), or null
     ldx_hit *hits;
     uint32_t *counts;              // [n_snps] or null: hits per query row, counted as they are appended (ldx_area_scan_dev)
-    // (two unions: the triangle's two launch-bookkeeping words share the storage of two band-only members -- kernel arguments
-    // live in scalar registers, and two more of them pushed the band kernel's register allocation into spilling INSIDE its
-    // K loop, whose hand-counted s_waitcnt vmcnt a scratch access breaks: tests/test_abi_and_host.py scans for that)
-    union {
-        unsigned long long *n_hits;   // band: the hit-slot counter
-        uint32_t *done_host;          // triangle: where the launch's last workgroup publishes launch_seq (pinned host memory:
-    };                                // the slot's entry of acquire_sched's PerDevice::done)
-    union {
-        uint64_t hit_cap;             // band
-        uint32_t launch_seq;          // triangle: this launch's number on its ticket-counter slot (acquire_sched)
-    };
+    // (kernel arguments live in scalar registers: two more of them once pushed the band kernel's register allocation into
+    // spilling INSIDE its K loop, whose hand-counted s_waitcnt vmcnt a scratch access breaks -- tests/test_abi_and_host.py
+    // scans for that; keep this struct at its size)
+    unsigned long long *n_hits;    // band: the hit-slot counter
+    uint64_t hit_cap;              // band
     double flank, k_thres;
     int measure;
     F32Const f32;                  // the fp32 epilogue tier's constants (triangle launches use only this member and the next)
@@ -417,6 +397,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
     // Infinity Cache (round 3: 450 MB of traffic for a 64 MB plane).  The triangle keeps the single counter: every one of its
     // tiles needs all rows below it, which no L2 holds.
     const uint32_t my_xcd = kArea ? (__builtin_amdgcn_s_getreg(63508) & 7u) : 0u;   // XCC_ID
+    uint32_t static_next = blockIdx.x;   // (thread 0 only) the last ticket of the round-robin order: launches without a workspace
     auto draw = [&]() -> uint32_t {
         if constexpr (kArea) {
             for (uint32_t k = 0; k < 8u; ++k) {   // the ranges are cut at TILES (eighths of the tile list): the plan's order is per range
@@ -429,7 +410,9 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
             return n_tickets;   // every range is exhausted
         } else {
             // the first gridDim.x tickets are the workgroups' own indices (no atomic round trip before a workgroup's first
-            // pass: ~1.5 us per launch); the counter hands out the rest (the grid never exceeds the tickets: launch_mfma)
+            // pass: ~1.5 us per launch); the counter hands out the rest (the grid never exceeds the tickets: launch_mfma).
+            // No workspace (sched == null): round-robin, workgroup b takes tickets b, b + grid, b + 2 grid ...
+            if (!sched) return static_next += gridDim.x;
             return gridDim.x + atomicAdd(&sched[0], 1u);
         }
     };
@@ -437,7 +420,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
     // stamps readable (K loop alone on the matrix pipe: 29.3k cycles per unit).  It buys nothing on the wall clock: the
     // two waves of a SIMD are bound by their combined instruction issue.
     uint32_t *ktok = nullptr;
-    if (!kArea && (ablate_arg & 4096)) {
+    if (!kArea && sched && (ablate_arg & 4096)) {
         const uint32_t hw = __builtin_amdgcn_s_getreg(63492), xcc = __builtin_amdgcn_s_getreg(63508);   // HW_ID, XCC_ID
         ktok = sched + 2u + ((((xcc & 7u) * 8u + ((hw >> 13) & 7u)) * 2u + ((hw >> 12) & 1u)) * 16u + ((hw >> 8) & 15u));
     }
@@ -451,7 +434,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
         const uint32_t ticket = tickets[parity];
         parity ^= 1u;
         if (ticket >= n_tickets) {   // block-uniform; the last workgroup out re-arms the counters
-            if (tid == 0 && atomicAdd(&sched[1], 1u) == gridDim.x - 1u) {
+            if (tid == 0 && sched && atomicAdd(&sched[1], 1u) == gridDim.x - 1u) {
                 // (agent-scope atomic stores, never plain ones: store_agent, ldx_common.h.  They go through to the memory side
                 // and are complete when acknowledged, so the order between them needs a wait for the acknowledgement, not a
                 // fence: __threadfence() -- and a release store -- write back the XCD's whole L2, result cells included, at
@@ -460,14 +443,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 if (kArea)
                     for (uint32_t x = 0; x < 8u; ++x) store_agent(&sched[2u + 32u * x], 0u);   // the per-XCD counters (over-drawn at the end)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                store_agent(&sched[0], 0u);
-                // the slot is re-armed: tell the host, which may now hand it to another stream (acquire_sched) -- a
-                // system-scope store into pinned host memory once the stores above are acknowledged: the host compares it
-                // with the number it issued, without a copy or a synchronisation.
-                if constexpr (!kArea) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __hip_atomic_store(aa.done_host, aa.launch_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                }
+                store_agent(&sched[0], 0u);   // the workspace is re-armed for the next launch that uses it
             }
             break;
         }
@@ -1506,170 +1482,15 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
             if (sl < aa.hit_cap) aa.hits[sl].query = 0xFFFFFFFFu;
 }
 
-// One ticket-counter slot per (device, stream): launches of one stream are ordered, so they may share it; launches of
-// different streams (or devices) may overlap, so they must not.  The slots live in the per-device instance of g_sched,
-// which the loader zero-fills; every launch leaves its slot re-armed (the last workgroup out resets the words with
-// agent-scope atomic stores), so a launch costs no memset node.  (ld_area's band keeps its counters in the caller's
-// workspace instead: area_mfma.)
-// Launches recorded under stream capture do not use the slots at all: each gets its own counters (g_capt above), so a
-// graph can be replayed on any stream, beside any other graph or eager launch.
-// Reclaiming (round 4).  A process that keeps creating streams (one per chromosome, per table ...) runs out of the 256
-// slots of a device.  Every launch carries a sequence number (AreaArgs::launch_seq) that its last workgroup publishes
-// when it ends; when no slot is free the host takes a slot whose last ISSUED launch has FINISHED -- whatever became of
-// the stream that owned it (destroyed, idle, reused).  The old owner, should it launch again, simply acquires a slot
-// anew.  Only when all 256 slots are in flight (or 65 536 launches have been captured) does the call fail: kNoSlot,
-// which the entry points turn into the popcount kernel for LDX_PATH_AUTO (identical results) and into
-// LDX_E_UNSUPPORTED for an explicit matrix-pipe path.
-// Round 5 (ADVICE r04 + VERDICT r04 item 8):
-//   * the finished-launch numbers are published into PINNED HOST memory (one word per slot, a system-scope release store
-//     by the launch's last workgroup), so the host reads them with a plain load -- no copy, no synchronisation;
-//   * a slot's sequence numbers are MONOTONE across owners: a reclaimed slot continues where the last owner stopped.
-//     (Round 4 restarted at 0: the new owner's first launch was number 1 while the host word still said 1 from the old
-//     owner's first launch, so until that launch finished the slot looked idle again and could be handed to a second
-//     stream.)  The number is issued in the same critical section that hands the slot out: there is no window in which
-//     a taken slot compares as finished;
-//   * a map hit is not trusted on the handle alone: the runtime recycles the handles of destroyed streams, and a stream
-//     destroyed with a launch in flight must not lend its slot to the next stream that happens to get its handle.  If the
-//     slot's last launch has NOT finished while the caller's stream reports no pending work (hipStreamQuery ==
-//     hipSuccess), that launch cannot have been issued on the caller's stream: the caller gets another slot, and the
-//     orphan is reclaimed like any other once its launch has ended.  The query costs ~3.5 us (+11 % on an eager launch of
-//     a 3 000-SNP panel, profiles/r05/kernel_end_ab.log), so it is skipped when the slot's previous launch was issued less
-//     than 50 us ago: no stream can have been destroyed and another created in that time (hipStreamCreate alone takes
-//     longer), and a loop of back-to-back launches never pays it.  (hipStreamGetId would identify the stream object, but
-//     the libamdhip64 that torch 2.10 loads does not export it.)
-static int acquire_sched(hipStream_t s, uint32_t **sched, uint32_t *launch_seq, uint32_t **done_host)
-{
-    struct Key {
-        int dev;
-        hipStream_t s;
-        bool operator==(const Key &o) const { return dev == o.dev && s == o.s; }
-    };
-    struct KeyHash {
-        size_t operator()(const Key &k) const { return std::hash<void *>()((void *)k.s) * 31u + (size_t)k.dev; }
-    };
-    struct Slot {
-        hipStream_t owner = nullptr;
-        std::chrono::steady_clock::time_point last{};   // when the last launch was issued (host clock)
-        uint32_t issued = 0;       // sequence number of the last launch issued on the slot (monotone across owners)
-        bool in_use = false;
-        bool owned = false;        // `owner` still maps to this slot (false: an orphan waiting for its launch to end)
-    };
-    struct PerDevice {
-        uint32_t (*pool)[kSchedWords] = nullptr;   // this device's g_sched
-        Slot slots[kSchedSlots];
-        uint32_t next_slot = 0;                    // slots handed out for the first time so far
-        uint32_t *done = nullptr;                  // [kSchedSlots + 1] pinned host memory: number of the last FINISHED launch
-        uint32_t *done_dev = nullptr;              // ... as the device addresses it (the last word: where captured launches write)
-        uint32_t (*capt)[kCaptWords] = nullptr;    // this device's g_capt
-        uint32_t next_capt = 0;                    // private counter sets handed to captured launches so far
-    };
-    static std::mutex sched_mutex;
-    static std::unordered_map<Key, uint32_t, KeyHash> sched_slot;
-    static PerDevice *per_dev[64] = {};
-    int dev = 0;
-    LDX_HIP(hipGetDevice(&dev));
-    LDX_REQUIRE(dev >= 0 && dev < 64, "device ordinal out of range");
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cap) != hipSuccess) {
-        (void)hipGetLastError();
-        cap = hipStreamCaptureStatusNone;
-    }
-    std::lock_guard<std::mutex> lock(sched_mutex);
-    if (!per_dev[dev]) per_dev[dev] = new PerDevice();
-    PerDevice &pd = *per_dev[dev];
-    if (!pd.pool) {
-        void *sym = nullptr;
-        LDX_HIP(hipGetSymbolAddress(&sym, HIP_SYMBOL(g_sched)));   // the current device's copy of the symbol
-        void *host = nullptr, *devp = nullptr;
-        void *csym = nullptr;
-        LDX_HIP(hipGetSymbolAddress(&csym, HIP_SYMBOL(g_capt)));
-        pd.capt = reinterpret_cast<uint32_t (*)[kCaptWords]>(csym);
-        LDX_HIP(hipHostMalloc(&host, (kSchedSlots + 1u) * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
-        memset(host, 0, (kSchedSlots + 1u) * sizeof(uint32_t));
-        LDX_HIP(hipHostGetDevicePointer(&devp, host, 0));
-        pd.done = (uint32_t *)host;
-        pd.done_dev = (uint32_t *)devp;
-        pd.pool = reinterpret_cast<uint32_t (*)[kSchedWords]>(sym);
-    }
-    auto finished = [&](uint32_t k) {   // the slot's last issued launch has ended (acquire: its re-arming stores came first)
-        return __atomic_load_n(&pd.done[k], __ATOMIC_ACQUIRE) == pd.slots[k].issued;
-    };
-    if (cap != hipStreamCaptureStatusNone) {   // a recorded launch: its own counters, nothing shared with any stream
-#ifndef LDX_TUNING   // (tuning builds keep the slots: their K-loop token lives behind the counters)
-        if (pd.next_capt >= kCaptSets) {
-            set_error("ld_triangle on the matrix pipe: %u launches have been recorded under stream capture on device %d; no "
-                      "private ticket counters are left", kCaptSets, dev);
-            return kNoSlot;
-        }
-        *sched = pd.capt[pd.next_capt++];
-        *launch_seq = 1u;
-        *done_host = pd.done_dev + kSchedSlots;   // (nobody reads it)
-        return LDX_OK;
-#endif
-    }
-    const Key key{dev, s};
-    const auto now = std::chrono::steady_clock::now();
-    uint32_t slot = 0;
-    bool have = false;
-    auto it = sched_slot.find(key);
-    if (it != sched_slot.end()) {
-        slot = it->second;
-        have = true;
-        Slot &c = pd.slots[slot];
-        if (cap == hipStreamCaptureStatusNone && !finished(slot) && now - c.last > std::chrono::microseconds(50)) {
-            const hipError_t q = hipStreamQuery(s);
-            if (q != hipSuccess) (void)hipGetLastError();   // hipErrorNotReady: the launch is the caller's own, still running
-            if (q == hipSuccess && !finished(slot)) {        // idle stream, unfinished launch: a recycled handle
-                c.owned = false;
-                sched_slot.erase(it);
-                have = false;
-            }
-        }
-    }
-    if (!have) {
-        if (pd.next_slot < kSchedSlots) {
-            slot = pd.next_slot++;
-        } else {   // all handed out: look for one whose last launch has finished
-            bool found = false;
-            for (uint32_t k = 0; k < kSchedSlots && !found; ++k) {
-                const Slot &c = pd.slots[k];
-                if (c.in_use && finished(k)) {
-                    if (c.owned) sched_slot.erase(Key{dev, c.owner});
-                    slot = k;
-                    found = true;
-                }
-            }
-            if (!found) {
-                set_error("ld_triangle on the matrix pipe: all %u ticket-counter slots of device %d are in flight", kSchedSlots, dev);
-                return kNoSlot;
-            }
-        }
-        const uint32_t keep = pd.slots[slot].issued;   // monotone across owners
-        pd.slots[slot] = Slot{};
-        pd.slots[slot].issued = keep;
-        pd.slots[slot].owner = s;
-        pd.slots[slot].in_use = true;
-        pd.slots[slot].owned = true;
-        sched_slot.emplace(key, slot);
-    }
-    Slot &mine = pd.slots[slot];
-    mine.last = now;
-    if (++mine.issued == 0u) mine.issued = 1u;   // (0 is what a never-used slot's host word says)
-    *launch_seq = mine.issued;
-    *sched = pd.pool[slot];
-    *done_host = pd.done_dev + slot;
-    return LDX_OK;
-}
-
 template <bool kRaw, bool kN11, bool kFp4, typename Cell>
 static int launch_mfma(const void *alt, const double *fa, const double *fr, const double *q, uint32_t n_snps,
                        uint32_t n_hap, uint64_t unit_begin, uint64_t unit_end, Cell *out, ldx_ld64 *out_raw,
-                       uint32_t *out_n11, hipStream_t s)
+                       uint32_t *out_n11, uint32_t *sched, hipStream_t s)
 {
     const uint32_t nch = n_chunks(n_hap);
     if ((uint64_t)n_slabs(n_snps) * nch * kSlab * 16u >= (1ull << 32)) {   // the K loop addresses the plane with 32-bit lane offsets
         set_error("ld_triangle on the matrix pipe: a bit plane of 4 GiB or more (%u SNPs x %u haplotypes)", n_snps, n_hap);
-        return kNoSlot;   // LDX_PATH_AUTO: the popcount kernel; an explicit matrix-pipe path: LDX_E_UNSUPPORTED
+        return kNoMatrixPath;   // LDX_PATH_AUTO: the popcount kernel; an explicit matrix-pipe path: LDX_E_UNSUPPORTED
     }
     const size_t lds = mfma_lds_bytes(kStatRows, kFp4 && !kRaw && !kN11);
     if (lds > 64u * 1024u) {   // above 64 KiB the dynamic LDS size needs the opt-in attribute: once per device
@@ -1714,9 +1535,7 @@ static int launch_mfma(const void *alt, const double *fa, const double *fr, cons
     uint64_t grid = slots;
     if (grid > (uint64_t)n_pass + n_short) grid = (uint64_t)n_pass + n_short;
     if (grid < 1) grid = 1;
-    uint32_t *sched = nullptr;
     AreaArgs tri_args{};
-    if (int rc = acquire_sched(s, &sched, &tri_args.launch_seq, &tri_args.done_host)) return rc;
     tri_args.f32 = f32_const((double)n_hap);
     int ablate = 0;
     unsigned long long *stamps = nullptr;
@@ -1751,15 +1570,18 @@ static int launch_mfma(const void *alt, const double *fa, const double *fr, cons
     return LDX_OK;
 }
 
+size_t triangle_mfma_workspace_bytes() { return kTriWorkspaceBytes; }
+
 int triangle_mfma(const void *alt, const double *fa, const double *fr, const double *q, uint32_t n_snps, uint32_t n_hap,
                   uint64_t unit_begin, uint64_t unit_end, int out_format, void *out, ldx_ld64 *out_raw, uint32_t *out_n11,
-                  bool fp4, hipStream_t s)
+                  bool fp4, void *workspace, hipStream_t s)
 {
+    uint32_t *const sched = (uint32_t *)workspace;   // null: round-robin passes (no counters)
 #define LDX_GO(R, N, CELL)                                                                                          \
     return fp4 ? launch_mfma<R, N, true, CELL>(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end, (CELL *)out,    \
-                                               out_raw, out_n11, s)                                                 \
+                                               out_raw, out_n11, sched, s)                                          \
                : launch_mfma<R, N, false, CELL>(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end, (CELL *)out,   \
-                                                out_raw, out_n11, s)
+                                                out_raw, out_n11, sched, s)
     if (out_format == LDX_OUT_K16) {   // no unrounded output beside the 4-byte cells (ldx_triangle_ex_dev checks)
         if (out_n11) LDX_GO(false, true, ldx_k16);
         LDX_GO(false, false, ldx_k16);
@@ -1917,7 +1739,7 @@ int area_mfma(const void *alt, const double *fa, const double *fr, const double 
     const uint32_t T = n_slabs(n_snps), nch = n_chunks(n_hap);
     if ((uint64_t)T * nch * kSlab * 16u >= (1ull << 32)) {   // the K loop addresses the plane with 32-bit lane offsets
         set_error("ld_area on the matrix pipe: a bit plane of 4 GiB or more (%u SNPs x %u haplotypes)", n_snps, n_hap);
-        return kNoSlot;
+        return kNoMatrixPath;
     }
     char *w = (char *)workspace;
     uint8_t *is_query = (uint8_t *)w;

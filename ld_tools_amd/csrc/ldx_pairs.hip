@@ -425,18 +425,33 @@ static int launch_triangle(const void *alt, const double *fa, const double *fr, 
     return LDX_OK;
 }
 
+extern "C" size_t ldx_triangle_workspace_bytes(void) { return ldx::triangle_mfma_workspace_bytes(); }
+
+extern "C" int ldx_triangle_workspace_init_dev(void *workspace, size_t workspace_bytes, void *stream)
+{
+    LDX_REQUIRE(workspace, "null pointer");
+    LDX_REQUIRE(workspace_bytes >= ldx::triangle_mfma_workspace_bytes(), "workspace too small (see ldx_triangle_workspace_bytes)");
+    LDX_HIP(hipMemsetAsync(workspace, 0, ldx::triangle_mfma_workspace_bytes(), (hipStream_t)stream));
+    return LDX_OK;
+}
+
 extern "C" int ldx_triangle_dev(const void *alt, const double *fa, const double *fr, const double *q,
                                 uint32_t n_snps, uint32_t n_hap, uint64_t unit_begin, uint64_t unit_end,
                                 ldx_ld32 *out, ldx_ld64 *out_raw, uint32_t *out_n11, void *stream)
 {
     return ldx_triangle_ex_dev(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end,
-                               g_triangle_path.load(std::memory_order_relaxed), LDX_OUT_LD32, out, out_raw, out_n11, stream);
+                               g_triangle_path.load(std::memory_order_relaxed), LDX_OUT_LD32, out, out_raw, out_n11, nullptr, 0,
+                               stream);
 }
 
 extern "C" int ldx_triangle_ex_dev(const void *alt, const double *fa, const double *fr, const double *q,
                                    uint32_t n_snps, uint32_t n_hap, uint64_t unit_begin, uint64_t unit_end, int path,
-                                   int out_format, void *out, ldx_ld64 *out_raw, uint32_t *out_n11, void *stream)
+                                   int out_format, void *out, ldx_ld64 *out_raw, uint32_t *out_n11, void *workspace,
+                                   size_t workspace_bytes, void *stream)
 {
+    LDX_REQUIRE(!workspace || workspace_bytes >= ldx::triangle_mfma_workspace_bytes(),
+                "workspace too small (see ldx_triangle_workspace_bytes)");
+    LDX_REQUIRE(!workspace || ((uintptr_t)workspace & 255u) == 0, "workspace must be 256-byte aligned");
     LDX_REQUIRE(alt && fa && fr && q && out, "null pointer");
     LDX_REQUIRE(known_path(path), "unknown path");
     LDX_REQUIRE(out_format == LDX_OUT_LD32 || out_format == LDX_OUT_K16, "unknown output format");
@@ -456,10 +471,10 @@ extern "C" int ldx_triangle_ex_dev(const void *alt, const double *fa, const doub
     hipStream_t s = (hipStream_t)stream;
     if (path != LDX_PATH_POPCOUNT) {   // AUTO = the FP4 matrix kernel (twice the int8 kernel's counting rate)
         const int rc = triangle_mfma(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end, out_format, out, out_raw, out_n11,
-                                     path != LDX_PATH_MFMA, s);
-        if (rc != ldx::kNoSlot) return rc;
+                                     path != LDX_PATH_MFMA, workspace, s);
+        if (rc != ldx::kNoMatrixPath) return rc;
         if (path != LDX_PATH_AUTO) return LDX_E_UNSUPPORTED;   // an explicit matrix-pipe path: say so (message set)
-        // AUTO and no ticket-counter slot for this stream: the popcount kernel gives the very same cells
+        // AUTO and a bit plane of 4 GiB or more: the popcount kernel gives the very same cells
     }
     if (out_format == LDX_OUT_K16) {
         ldx_k16 *o = (ldx_k16 *)out;

@@ -64,6 +64,9 @@ class TriangleResult:
     n11: Optional[torch.Tensor] = None       # int32   [(units)*1024]     alt/alt haplotype counts
     k16: Optional[torch.Tensor] = None       # int16   [(units)*1024, 2]  bit patterns of the uint16 cells
     panel: Optional[PackedPanel] = None      # the panel the result came from (resolves escape cells)
+    ws: Optional[torch.Tensor] = None        # the matrix kernel's pass-scheduler workspace (include/ldx.h, ldx_triangle_ex_dev):
+                                             # zeroed once here, re-armed by every launch; one per result buffer, because two
+                                             # launches that may overlap write different buffers
 
     @property
     def fmt(self) -> str:
@@ -169,10 +172,13 @@ def ld_triangle(panel: PackedPanel, unit_range: Optional[Tuple[int, int]] = None
     out.panel = panel
     if cells:
         pcode = lib.ldx_get_triangle_path() if path is None else PATHS[path]
+        if out.ws is None and pcode != PATHS["popcount"]:
+            out.ws = torch.zeros(lib.ldx_triangle_workspace_bytes(), dtype=torch.uint8, device=dev)
         check(lib.ldx_triangle_ex_dev(panel.alt.data_ptr(), panel.fa.data_ptr(), panel.fr.data_ptr(),
                                       panel.q.data_ptr(), panel.n_snps, panel.n_hap, u0, u1, pcode,
                                       _lib.FORMATS[fmt], out.cells.data_ptr(), _ptr(out.raw), _ptr(out.n11),
-                                      _stream_ptr()), "ldx_triangle_ex_dev")
+                                      _ptr(out.ws), 0 if out.ws is None else out.ws.numel(), _stream_ptr()),
+              "ldx_triangle_ex_dev")
     return out
 
 

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(_lib.lib, n), f"{n} declared in ldx.h but not exported by libldx.so"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature in ld_tools_amd/_lib.py"
     assert set(_lib.SIGNATURES) == set(names)
-    assert _lib.version() == 101
+    assert _lib.version() == 102
 
 
 def test_no_torch_or_python_dependency_in_library():

@@ -3,10 +3,15 @@
 Bar: bit-exact for counts, packed planes, the 4-decimal results (k = value * 10^4) and the int-0 /
 float-0.0 flags; 1e-6 (in fact ~1e-15) for the unrounded D' and r^2 floats.
 """
+import sys
+from pathlib import Path
+
 import numpy as np
 import pytest
 
 from conftest import PANELS, tri_pairs
+
+ROOT = Path(__file__).resolve().parent.parent
 
 pytestmark = pytest.mark.gpu
 
@@ -781,8 +786,8 @@ def test_fp32_tier_parks_the_rows_and_columns_of_odd_snps(gpu):
 
 
 def test_triangle_on_many_streams(gpu):
-    """The pass scheduler keeps one ticket-counter pair per stream in a pool of 256: more streams than that, used one
-    after another and two at a time, still give the single-stream result."""
+    """Many streams, used one after another and two at a time, each launch with its own result buffer and therefore its own
+    pass-scheduler workspace (TriangleResult.ws): the single-stream result every time."""
     import torch
     from ld_tools_amd import PackedPanel, ld_triangle, synth
 
@@ -965,12 +970,13 @@ def test_area_repeated_queries_are_one_query(gpu, area_path):
 
 
 def test_triangle_on_a_thousand_raw_streams(gpu):
-    """a driver that creates a raw hipStream_t per chromosome / table must not run out of ticket-counter
-    slots (256 per device).  1 000 streams made with hipStreamCreate (ctypes on libamdhip64: torch recycles a pool of 32,
-    so torch.cuda.Stream cannot reach the limit) are used once each with an EXPLICIT matrix-pipe path and destroyed: the
-    library takes back the slot of a stream whose last launch has finished.  Every result equals the single-stream one.
-    Then 300 streams are kept alive and busy at once -- more launches in flight than slots: with LDX_PATH_AUTO the surplus
-    falls back to the popcount kernel (same cells), with an explicit path it is refused loudly."""
+    """a driver that creates a raw hipStream_t per chromosome / table.  Rounds 3-5 kept the
+    matrix kernel's ticket counters in a pool of 256 (device, stream) slots inside the library; since round 6 they live in the
+    CALLER's workspace (include/ldx.h, ldx_triangle_ex_dev), so there is nothing to run out of: 1 000 streams made with
+    hipStreamCreate (ctypes on libamdhip64: torch recycles a pool of 32) are used once each with an EXPLICIT matrix-pipe path
+    and destroyed -- one shared workspace, because the launches follow one another -- then 300 streams are kept alive and busy
+    at once, a workspace each; then recycled stream handles with launches still queued (the old pool could
+    hand one slot to two live launches there).  Every result equals the single-stream one; no launch is ever refused."""
     import ctypes
     import torch
     from ld_tools_amd import PackedPanel, _lib, ld_triangle, synth
@@ -985,65 +991,152 @@ def test_triangle_on_a_thousand_raw_streams(gpu):
     torch.cuda.synchronize()
     cells = ref.k16.numel() // 2
     out = torch.empty_like(ref.k16)
+    ws_bytes = lib.ldx_triangle_workspace_bytes()
 
-    def launch(stream, path, dst):
-        return lib.ldx_triangle_ex_dev(p.alt.data_ptr(), p.fa.data_ptr(), p.fr.data_ptr(), p.q.data_ptr(), p.n_snps, p.n_hap,
-                                       0, p.n_units, path, _lib.FORMATS["k16"], dst.data_ptr(), None, None, stream)
+    def workspace():
+        return torch.zeros(ws_bytes, dtype=torch.uint8, device=p.device)
 
+    def launch(stream, path, dst, ws, panel=p):
+        return lib.ldx_triangle_ex_dev(panel.alt.data_ptr(), panel.fa.data_ptr(), panel.fr.data_ptr(), panel.q.data_ptr(),
+                                       panel.n_snps, panel.n_hap, 0, panel.n_units, path, _lib.FORMATS["k16"], dst.data_ptr(),
+                                       None, None, ws.data_ptr(), ws_bytes, stream)
+
+    shared = workspace()
     for k in range(1000):
         st = ctypes.c_void_p()
         assert hip.hipStreamCreate(ctypes.byref(st)) == 0
         out.fill_(-1)
         torch.cuda.synchronize()
-        rc = launch(st, 3, out)                      # LDX_PATH_FP4, explicit: no popcount fallback may hide a failure
+        rc = launch(st, 3, out, shared)              # LDX_PATH_FP4, explicit: no popcount fallback may hide a failure
         assert rc == 0, (k, rc, lib.ldx_last_error())
         assert hip.hipStreamSynchronize(st) == 0
         assert torch.equal(out, ref.k16), k
         assert hip.hipStreamDestroy(st) == 0
     assert out.numel() == 2 * cells
-    # more streams in flight than slots: a long kernel on each of 300 live streams
+    assert int(shared.view(torch.int32)[:8].abs().sum().item()) == 0      # every launch left the counters re-armed
+    # 300 live streams, a long matrix-pipe kernel in flight on each (the old pool had 256 slots)
     big = PackedPanel.from_codes(synth.synth_codes_device(6000, 1008, seed=3))
     bref = ld_triangle(big, fmt="k16", path="popcount")
     torch.cuda.synchronize()
-    outs, streams, refused = [], [], 0
+    outs, streams, spaces = [], [], []
     for k in range(300):
         st = ctypes.c_void_p()
         assert hip.hipStreamCreate(ctypes.byref(st)) == 0
         streams.append(st)
         o = torch.empty_like(bref.k16)
-        rc = lib.ldx_triangle_ex_dev(big.alt.data_ptr(), big.fa.data_ptr(), big.fr.data_ptr(), big.q.data_ptr(), big.n_snps,
-                                     big.n_hap, 0, big.n_units, 0, _lib.FORMATS["k16"], o.data_ptr(), None, None, st)   # AUTO
+        spaces.append(workspace())
+        rc = launch(st, 3 if k & 1 else 0, o, spaces[-1], big)       # explicit FP4 / AUTO alternately: never refused
         assert rc == 0, (k, rc, lib.ldx_last_error())
         outs.append(o)
-        if k >= 280:                                 # by now every slot may be taken and busy: an explicit path must say so
-            rc = launch(st, 3, out)
-            assert rc in (0, -3), rc                 # LDX_OK or LDX_E_UNSUPPORTED -- never somebody else's counters
-            refused += rc == -3
     for st in streams:
         assert hip.hipStreamSynchronize(st) == 0
     for k, o in enumerate(outs):
         assert torch.equal(o, bref.k16), k
     for st in streams:
         assert hip.hipStreamDestroy(st) == 0
-    print(f"explicit-path launches refused while all slots were busy: {refused} of 20")
-    # every slot has been handed out by now, so a new stream RECLAIMS one.  The new owner's launch sits behind a
-    # long kernel of its own stream (a popcount triangle: no slot involved) when a second new stream asks for a slot: it must
-    # not be handed the one just taken (round 4 restarted a reclaimed slot's sequence numbers, so until the new owner's first
-    # launch had run the slot compared as idle again).  Both launches, and a few more rounds of the same, must be right.
+    # recycled handles: a stream is destroyed with its launch still queued behind a long kernel, the next stream created may
+    # get its handle and launches at once on its own workspace; both results must be right (nothing is keyed by the handle)
     for rnd in range(6):
         sx, sy = ctypes.c_void_p(), ctypes.c_void_p()
-        assert hip.hipStreamCreate(ctypes.byref(sx)) == 0 and hip.hipStreamCreate(ctypes.byref(sy)) == 0
+        assert hip.hipStreamCreate(ctypes.byref(sx)) == 0
         blocker = torch.empty_like(bref.k16)
         ox, oy = torch.full_like(ref.k16, -1), torch.full_like(ref.k16, -1)
+        wx, wy, wb = workspace(), workspace(), workspace()
         torch.cuda.synchronize()
-        rc = lib.ldx_triangle_ex_dev(big.alt.data_ptr(), big.fa.data_ptr(), big.fr.data_ptr(), big.q.data_ptr(), big.n_snps,
-                                     big.n_hap, 0, big.n_units, 1, _lib.FORMATS["k16"], blocker.data_ptr(), None, None, sx)   # POPCOUNT: ~ms
-        assert rc == 0
-        assert launch(sx, 3, ox) == 0, lib.ldx_last_error()      # queued behind the blocker, on a reclaimed slot
-        assert launch(sy, 3, oy) == 0, lib.ldx_last_error()      # asks for a slot while that launch has not even started
-        assert hip.hipStreamSynchronize(sx) == 0 and hip.hipStreamSynchronize(sy) == 0
+        assert launch(sx, 1, blocker, wb, big) == 0              # POPCOUNT: ~ms
+        assert launch(sx, 3, ox, wx) == 0, lib.ldx_last_error()  # queued behind the blocker
+        assert hip.hipStreamDestroy(sx) == 0                     # destroyed with work in flight (HIP finishes it)
+        assert hip.hipStreamCreate(ctypes.byref(sy)) == 0        # may well be sx's handle again
+        assert launch(sy, 3, oy, wy) == 0, lib.ldx_last_error()
+        assert hip.hipStreamSynchronize(sy) == 0
+        torch.cuda.synchronize()
         assert torch.equal(ox, ref.k16) and torch.equal(oy, ref.k16), rnd
-        assert hip.hipStreamDestroy(sx) == 0 and hip.hipStreamDestroy(sy) == 0
+        assert hip.hipStreamDestroy(sy) == 0
+
+
+def test_triangle_without_a_workspace_deals_passes_round_robin(gpu):
+    """include/ldx.h: workspace = NULL is allowed -- the passes are dealt round-robin, no counter anywhere -- and gives the same
+    cells (ldx_triangle_dev, the plain entry point, runs that way).  Panels of less than one round, a few rounds and with
+    halved passes; both matrix kernels; launches on two streams at once, which would share nothing."""
+    import torch
+    from ld_tools_amd import PackedPanel, _lib, ld_triangle, synth
+    from ld_tools_amd._lib import lib
+
+    for n, h, seed in ((700, 1008, 5), (9000, 1008, 6), (5000, 5008, 7)):
+        p = PackedPanel.from_codes(synth.synth_codes_device(n, h, seed=seed))
+        ref = ld_triangle(p, fmt="k16", path="popcount")
+        ref32 = ld_triangle(p, fmt="ld32", path="popcount")
+        torch.cuda.synchronize()
+        for path in (3, 2, 0):
+            outs = [torch.full_like(ref.k16, -1) for _ in range(2)]
+            streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+            for o, st in zip(outs, streams):
+                rc = lib.ldx_triangle_ex_dev(p.alt.data_ptr(), p.fa.data_ptr(), p.fr.data_ptr(), p.q.data_ptr(), p.n_snps, p.n_hap,
+                                             0, p.n_units, path, _lib.FORMATS["k16"], o.data_ptr(), None, None, None, 0,
+                                             st.cuda_stream)
+                assert rc == 0, lib.ldx_last_error()
+            torch.cuda.synchronize()
+            for o in outs:
+                assert torch.equal(o, ref.k16), (n, h, path)
+        o32 = torch.full_like(ref32.ld32, float("nan"))
+        rc = lib.ldx_triangle_dev(p.alt.data_ptr(), p.fa.data_ptr(), p.fr.data_ptr(), p.q.data_ptr(), p.n_snps, p.n_hap, 0,
+                                  p.n_units, o32.data_ptr(), None, None, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, lib.ldx_last_error()
+        torch.cuda.synchronize()
+        assert torch.equal(o32.view(torch.int32), ref32.ld32.view(torch.int32)), (n, h)
+
+
+def test_seventy_thousand_captured_triangle_launches(gpu):
+    """rounds 5's captured launches each consumed a private counter set for good -- 65 536 per process and
+    device, after which LDX_PATH_AUTO silently ran the 5x slower popcount kernel.  70 graphs of 1 000 launches each are
+    captured here (and dropped again) with an EXPLICIT FP4 path: none is refused, and the last graph still computes the
+    triangle.  The workspace is the result's own (TriangleResult.ws)."""
+    import torch
+    from ld_tools_amd import PackedPanel, ld_triangle, synth
+
+    p = PackedPanel.from_codes(synth.synth_codes_device(200, 256, seed=12))
+    ref = ld_triangle(p, fmt="k16", path="popcount")
+    out = ld_triangle(p, fmt="k16", path="fp4")
+    torch.cuda.synchronize()
+    g = None
+    for k in range(70):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(1000):
+                ld_triangle(p, out=out, fmt="k16", path="fp4")
+        if k % 23 == 0 or k == 69:
+            out.cells.fill_(-1)
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out.cells, ref.cells), k
+    del g
+
+
+def test_first_triangle_launch_of_a_process_under_capture(gpu):
+    """the first matrix-pipe launch of a process used to allocate pinned host memory (the old slot pool's
+    finished-launch words), which HIP refuses on a capturing thread.  Nothing is allocated at launch any more; a fresh process
+    whose FIRST ld_triangle call of the panel's shape is recorded under capture gets the right triangle."""
+    import subprocess
+
+    code = (
+        "import torch\n"
+        "from ld_tools_amd import PackedPanel, ld_triangle, synth\n"
+        "from ld_tools_amd import ops\n"
+        "from ld_tools_amd._lib import lib\n"
+        "p = PackedPanel.from_codes(synth.synth_codes_device(5000, 1008, seed=3))\n"
+        "cells = p.n_units * 1024\n"
+        "out = ops.TriangleResult(p.n_snps, 0, p.n_units, k16=torch.full((cells, 2), -1, dtype=torch.int16, device=p.device),\n"
+        "                         ws=torch.zeros(lib.ldx_triangle_workspace_bytes(), dtype=torch.uint8, device=p.device))\n"
+        "torch.cuda.synchronize()\n"
+        "g = torch.cuda.CUDAGraph()\n"
+        "with torch.cuda.graph(g):\n"
+        "    ld_triangle(p, out=out, fmt='k16', path='fp4')\n"
+        "g.replay(); torch.cuda.synchronize()\n"
+        "ref = ld_triangle(p, fmt='k16', path='popcount'); torch.cuda.synchronize()\n"
+        "assert torch.equal(out.cells, ref.cells)\n"
+        "print('CAPTURE_FIRST_OK')\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=str(ROOT))
+    assert r.returncode == 0 and "CAPTURE_FIRST_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
 
 def test_triangle_100k_shard_of_eight(gpu):
