@@ -55,6 +55,8 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--repeats", type=int, default=7,
+                    help="timed regions of --steps steps each; the line reports the median region (and all of them)")
     ap.add_argument("--snps", type=int, default=0, help="panel size (default: 10 000 at N = 1, 100 000 at N > 1)")
     ap.add_argument("--haps", type=int, default=5008)
     ap.add_argument("--fmt", default="k16", choices=("k16", "ld32"),
@@ -264,6 +266,20 @@ def other_workloads(torch, dev, fmt, bench_codes, scale="full", corrupt=False):
     small = scale != "full"
     res = {}
     cell_bytes = 4 if fmt == "k16" else 8
+    import statistics
+
+    def timed_launches(fn, reps):
+        """`reps` launches of fn() back to back, HIP events around each on the launch stream: (median, min, all) in ms."""
+        evs = []
+        for _ in range(reps):
+            a, c = events()
+            a.record()
+            fn()
+            c.record()
+            evs.append((a, c))
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(c) for a, c in evs]
+        return statistics.median(ms), min(ms), ms
     # ---- configs[4]: ld_triangle 50 000 x 1008 (EUR sub-panel), the HBM-write regime ----
     n, h = (6000, 1008) if small else (50000, 1008)
     key4 = f"ld_triangle {n}x{h}"
@@ -274,14 +290,8 @@ def other_workloads(torch, dev, fmt, bench_codes, scale="full", corrupt=False):
             ld_triangle(p, out=o, fmt=fmt)      # (the headline's settle_steps, for this leg; reported as settle_launches)
         torch.cuda.synchronize()
         o.cells.fill_(-1)
-        reps = 8
-        a, c = events()
-        a.record()
-        for _ in range(reps):
-            ld_triangle(p, out=o, fmt=fmt)
-        c.record()
-        torch.cuda.synchronize()
-        ms = a.elapsed_time(c) / reps
+        reps = 9
+        ms, ms_min, ms_all = timed_launches(lambda: ld_triangle(p, out=o, fmt=fmt), reps)
         if corrupt:                                              # test hook (--debug-corrupt-other)
             o.cells.view(torch.int32).view(-1)[4321] ^= 1
         chk = ld_triangle(p, fmt=fmt, path="popcount")          # the independent kernel (AND + popcount, fp64 epilogue)
@@ -291,7 +301,8 @@ def other_workloads(torch, dev, fmt, bench_codes, scale="full", corrupt=False):
         pairs = n * (n - 1) // 2
         alg = float(cell_bytes) * pairs + lib.ldx_plane_bytes(n, h)
         res[key4] = {
-            "ms": ms, "pairs_per_s": pairs / (ms * 1e-3), "fmt": fmt, "verified_against": "popcount kernel, every cell",
+            "ms": ms, "ms_min": ms_min, "ms_runs": ms_all, "timing": "median of the launches (HIP events around each)",
+            "pairs_per_s": pairs / (ms * 1e-3), "fmt": fmt, "verified_against": "popcount kernel, every cell",
             "results_equal": same, "launches": reps, "settle_launches": 3 if small else 40,
             "roofline_hbm": {"bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": alg},
@@ -315,19 +326,10 @@ def other_workloads(torch, dev, fmt, bench_codes, scale="full", corrupt=False):
             ld_triangle(p, out=o, fmt=fmt)
             torch.cuda.synchronize()
             o.cells.fill_(-1)
-            reps, kms = 4, []
-            a, c = events()
-            a.record()
-            for _ in range(reps):
-                k0, k1 = events()
-                k0.record()
-                ld_triangle(p, out=o, fmt=fmt)
-                k1.record()
-                kms.append((k0, k1))
-            c.record()
-            torch.cuda.synchronize()
-            ms = a.elapsed_time(c) / reps
-            kern_ms = sum(x.elapsed_time(y) for x, y in kms) / reps
+            reps = 5
+            t0 = time.perf_counter()
+            kern_ms, kern_min, kern_all = timed_launches(lambda: ld_triangle(p, out=o, fmt=fmt), reps)
+            ms = kern_ms            # (a launch is ~10 ms: the events around it are the step)
             # verification: whole unit ranges of the eight-way partition, recomputed by the popcount kernel
             parts = ldist.unit_partition(n, 8)
             checked, same = [], True
@@ -343,7 +345,8 @@ def other_workloads(torch, dev, fmt, bench_codes, scale="full", corrupt=False):
             alg_ops = 2.0 * h * pairs
             alg = float(cell_bytes) * pairs + lib.ldx_plane_bytes(n, h)
             res[key3] = {
-                "ms": ms, "pairs_per_s": pairs / (ms * 1e-3), "fmt": fmt, "launches": reps,
+                "ms": ms, "ms_min": kern_min, "ms_runs": kern_all, "timing": "median of the launches (HIP events around each)",
+                "pairs_per_s": pairs / (ms * 1e-3), "fmt": fmt, "launches": reps,
                 "verified_against": f"popcount kernel, every cell of unit ranges {checked} of unit_partition({n}, 8)",
                 "results_equal": same,
                 "roofline": {"bound": "mfma", "achieved": alg_ops / (kern_ms * 1e-3) / 1e12, "peak": MFMA_FP4_PEAK_TOPS,
@@ -364,16 +367,17 @@ def other_workloads(torch, dev, fmt, bench_codes, scale="full", corrupt=False):
             for _ in range(2):
                 ld_area(p, pos, None, 500000, "r_square", 0.8, check_positions=False)
             torch.cuda.synchronize()
-            reps, ev, scan_ms = 5, [], 0.0
-            t0 = time.perf_counter()
+            reps, ev, walls, scans = 7, [], [], []
             for _ in range(reps):       # the product call: from its second repetition on the launches are one HIP graph
+                t0 = time.perf_counter()
                 hits = ld_area(p, pos, None, 500000, "r_square", 0.8, check_positions=False)
                 torch.cuda.synchronize()
-            wall = (time.perf_counter() - t0) / reps
+                walls.append(time.perf_counter() - t0)
             for _ in range(reps):       # the scan alone: HIP events need the launches issued one by one
                 ld_area(p, pos, None, 500000, "r_square", 0.8, check_positions=False, events=ev)
                 torch.cuda.synchronize()
-                scan_ms += ev[0].elapsed_time(ev[1])
+                scans.append(ev[0].elapsed_time(ev[1]))
+            wall, scan_ms = statistics.median(walls), statistics.median(scans)
             old = ops.get_area_path()
             try:
                 ops.set_area_path("popcount")                        # the independent scan kernel
@@ -385,7 +389,9 @@ def other_workloads(torch, dev, fmt, bench_codes, scale="full", corrupt=False):
             n_pairs = hits.n_pairs
             res[key2] = {
                 "end_to_end_ms": wall * 1e3, "ordered_pairs": n_pairs, "ordered_pairs_per_s": n_pairs / wall, "hits": len(hits),
-                "scan_ms": scan_ms / reps, "scan": "ldx_area_scan_dev: query mask, band plan, FP4 band kernel (HIP events, eager launches)",
+                "scan_ms": scan_ms, "scan": "ldx_area_scan_dev: query mask, band plan, FP4 band kernel (HIP events, eager launches)",
+                "end_to_end_ms_min": min(walls) * 1e3, "end_to_end_ms_runs": [w * 1e3 for w in walls], "scan_ms_min": min(scans),
+                "scan_ms_runs": scans, "timing": f"medians of {reps} calls each",
                 "end_to_end": "positions resident on the device; scan (counting per query) + offsets / scatter / order kernels replayed "
                               "as one HIP graph + one host read",
                 "verified_against": "popcount scan, every hit in order", "results_equal": same}
@@ -394,6 +400,52 @@ def other_workloads(torch, dev, fmt, bench_codes, scale="full", corrupt=False):
             res[key2] = {"error": f"{type(exc).__name__}: {exc}"}
         del p
         torch.cuda.empty_cache()
+    # ---- panels that are NOT all "ordinary" (VERDICT r05 item 2), each timed INTERLEAVED with its clean twin (same seed, same
+    #      box, same minute) and checked against the popcount kernel: (i) configs[4]'s shape with 30 % of the SNPs
+    #      monomorphic -- what an EUR-size sub-panel of the ALL-panel variants an ld_area window returns looks like
+    #      (ld_area.py:215-225; the reference maps such pairs to the int 0, calc_ld.py:55-76,89-90); (ii) 40 000 x 5008 with
+    #      0.1 % code 2 in 20 % of the rows (a + r < n).  Rounds 1-5 measured only panels with 0.07 % such SNPs. ----
+    odd_legs = [((6000, 1008) if small else (50000, 1008), "30 % of rows monomorphic", dict(mono=0.3)),
+                ((5000, 5008) if small else (40000, 5008), "0.1 % code-2 in 20 % of rows", dict(miss=0.001, miss_rows=0.2))]
+    for (n, h), what, kw in odd_legs:
+        key = f"ld_triangle {n}x{h}, {what}"
+        try:
+            pc = PackedPanel.from_codes(synth.synth_codes_device(n, h, seed=synth.BENCH_SEED, device=dev))
+            po = PackedPanel.from_codes(synth.synth_codes_device(n, h, seed=synth.BENCH_SEED, device=dev, **kw))
+            oc, oo = ld_triangle(pc, fmt=fmt), ld_triangle(po, fmt=fmt)
+            for _ in range(3 if small else 12):
+                ld_triangle(pc, out=oc, fmt=fmt)
+                ld_triangle(po, out=oo, fmt=fmt)
+            torch.cuda.synchronize()
+            oo.cells.fill_(-1)
+            reps, evc, evo = 7, [], []
+            for _ in range(reps):
+                for pp, out_, lst in ((pc, oc, evc), (po, oo, evo)):
+                    a, c = events()
+                    a.record()
+                    ld_triangle(pp, out=out_, fmt=fmt)
+                    c.record()
+                    lst.append((a, c))
+            torch.cuda.synchronize()
+            msc = [a.elapsed_time(c) for a, c in evc]
+            mso = [a.elapsed_time(c) for a, c in evo]
+            chk = ld_triangle(po, fmt=fmt, path="popcount")
+            torch.cuda.synchronize()
+            same = bool(torch.equal(chk.cells.view(torch.int32), oo.cells.view(torch.int32)))
+            del chk
+            pairs = n * (n - 1) // 2
+            m_c, m_o = statistics.median(msc), statistics.median(mso)
+            res[key] = {"ms": m_o, "ms_min": min(mso), "ms_runs": mso, "pairs_per_s": pairs / (m_o * 1e-3),
+                        "clean_twin_ms": m_c, "clean_twin_ms_runs": msc, "slower_than_clean_twin": m_o / m_c - 1.0,
+                        "non_ordinary_snps": {"acnt_zero_or_full": int(((po.acnt[:n] == 0) | (po.acnt[:n] == h)).sum().item()),
+                                              "with_missing_codes": int(((po.acnt[:n] + po.rcnt[:n]) < h).sum().item())},
+                        "fmt": fmt, "launches": reps, "timing": "clean twin and this panel launched alternately; medians",
+                        "verified_against": "popcount kernel, every cell", "results_equal": same}
+            del pc, po, oc, oo
+            torch.cuda.empty_cache()
+        except Exception as exc:   # noqa: BLE001
+            res[key] = {"error": f"{type(exc).__name__}: {exc}"}
+            torch.cuda.empty_cache()
     # ---- pack and host-to-device of the bench panel's codes (reported separately, not in pairs/s) ----
     try:
         ns, nh = bench_codes.shape
@@ -571,12 +623,20 @@ def run_rank(args):
             settle_done = settle
     if out is not None:
         out.cells.fill_(-1)                # the timed steps must produce every result again (checked below)
-    if graph is not None:
-        dt, span_ms = timed_region(graph.replay)
-        kern_ms = span_ms / args.steps
-    else:
-        dt, _ = timed_region(lambda: run_steps(args.steps, timed=True))
-        kern_ms = sum(a.elapsed_time(b_) for a, b_ in zip(ev_k0, ev_k1)) / args.steps
+    # "3 warm-ups, 10 timed, report median and min".  The timed region -- EXACTLY K steps between barrier +
+    # synchronize on both sides -- is repeated R = 7 times (the same graph; the output was poisoned once, before the first);
+    # `ms_per_step`, `value` and `roofline.frac` come from the MEDIAN region, all R are printed (ms_per_step_runs) with their
+    # minimum beside them: one 2.5-ms region on a pool whose boxes differ by 8 % is not a measurement.
+    repeats = max(1, args.repeats)
+    runs = []           # (host seconds of the region, event span ms per step)
+    for _ in range(repeats):
+        if graph is not None:
+            dt_r, span_ms = timed_region(graph.replay)
+            km = span_ms / args.steps
+        else:
+            dt_r, _ = timed_region(lambda: run_steps(args.steps, timed=True))
+            km = sum(a.elapsed_time(b_) for a, b_ in zip(ev_k0, ev_k1)) / args.steps
+        runs.append((dt_r, km))
 
     def allmax(x):
         if not use_dist or world == 1:
@@ -585,7 +645,13 @@ def run_rank(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t[0].item()), -float(t[1].item())
 
-    dt, _ = allmax(dt)
+    # max over ranks PER REGION (a region ends when its slowest rank does), then the median region
+    per_region = [allmax(r[0])[0] for r in runs]
+    order = sorted(range(repeats), key=lambda i: per_region[i])
+    mid = order[(repeats - 1) // 2]                      # the median region (the lower one of an even count)
+    dt = per_region[mid]
+    dt_min = per_region[order[0]]
+    kern_ms = runs[mid][1]
     cold_dt, _ = allmax(cold_dt)
     kern_ms_max, kern_ms_min = allmax(kern_ms)
 
@@ -670,7 +736,11 @@ def run_rank(args):
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3,
+        "ms_per_step": dt / args.steps * 1e3,               # the MEDIAN of the R timed regions below (value, roofline: from it)
+        "ms_per_step_min": dt_min / args.steps * 1e3,
+        "ms_per_step_runs": [x / args.steps * 1e3 for x in per_region],   # every timed region of K steps, in run order
+        "timing": f"{repeats} timed regions of {args.steps} steps each (barrier + synchronize on both sides, max over ranks "
+                  "per region); ms_per_step / value / roofline.frac from the median region",
         "cold_ms_per_step": cold_dt / args.steps * 1e3,     # the same K steps from idle clocks, eager launches
         "higher_is_better": True,
         "scaling": "strong",
@@ -708,6 +778,21 @@ def run_rank(args):
         roofline["kernel_ms_includes_exchange"] = True
     elif use_dist:                       # eager: exchange = step time minus the kernel's own events
         line["config"]["exchange_ms_per_step"] = max(0.0, dt / args.steps * 1e3 - kern_ms_max)
+    if use_dist:
+        # Per rank: its kernel time, what its step spends outside the kernel (the exposed part of the
+        # exchange) and its share of the pairs -- the first record of a real multi-GPU node then shows at a glance whether
+        # the contiguous unit ranges are balanced and whether the all-gather hides under the kernel.
+        from ld_tools_amd._lib import UNIT_PAIRS as _UP
+        mine = {"rank": rank, "kernel_ms": kern_ms, "step_ms": runs[mid][0] / args.steps * 1e3,
+                "exchange_ms_per_step": (None if graph is not None else max(0.0, runs[mid][0] / args.steps * 1e3 - kern_ms)),
+                "units": int(u1 - u0), "cells": int(u1 - u0) * _UP,
+                "pairs": ldist.pairs_in_units(n_snps, u0, u1), "device": dev_id}
+        per_rank = [None] * world
+        if world > 1:
+            dist.all_gather_object(per_rank, mine)
+        else:
+            per_rank = [mine]
+        line["per_rank"] = per_rank
 
     def leg(leg_path, leg_fmt, reps):
         """Another kernel path / cell format on the same resident panel (N = 1), eager launches at settled clocks."""

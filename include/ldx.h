@@ -292,6 +292,14 @@ int ldx_get_area_path(void);
 int ldx_synth_codes_dev(int8_t *codes, uint32_t n_snps, uint32_t n_hap, size_t ld_codes,
                         uint64_t seed, const uint64_t *thresholds, uint64_t rho_thr,
                         uint32_t block_len, uint64_t miss_thr, uint32_t snp_offset, void *stream);
+/* The same with SNPs that are not "ordinary" (what a sub-panel of the ALL-panel variants holds: ld_area.py:215-225 takes
+ * every rs variant of the window, monomorphic in the sub-panel or not): mono_thr = probability * 2^64 that a SNP is
+ * monomorphic (every code 0; one in eight of them every code 1), miss_rows_thr = probability * 2^64 that a SNP carries the
+ * miss_thr codes at all (2^64 - 1: every SNP, as ldx_synth_codes_dev). */
+int ldx_synth_codes_ex_dev(int8_t *codes, uint32_t n_snps, uint32_t n_hap, size_t ld_codes,
+                           uint64_t seed, const uint64_t *thresholds, uint64_t rho_thr,
+                           uint32_t block_len, uint64_t miss_thr, uint32_t snp_offset,
+                           uint64_t mono_thr, uint64_t miss_rows_thr, void *stream);
 
 /* ---- host-pointer conveniences (same kernels; allocate, copy, synchronise) ------------- */
 /* calc_ld for ONE pair of code vectors of lengths h1, h2 (zip semantics of calc_ld.py:30-31:

@@ -132,6 +132,7 @@ SIGNATURES = {
     "ldx_set_area_path": (_int, [_int]),
     "ldx_get_area_path": (_int, []),
     "ldx_synth_codes_dev": (_int, [_vp, _u32, _u32, _sz, _u64, _vp, _u64, _u32, _u64, _u32, _vp]),
+    "ldx_synth_codes_ex_dev": (_int, [_vp, _u32, _u32, _sz, _u64, _vp, _u64, _u32, _u64, _u32, _u64, _u64, _vp]),
     "ldx_calc_ld_host": (_int, [_vp, _u32, _vp, _u32, _vp, _vp, _vp, _vp, _vp]),
     "ldx_probe_andpop_dev": (_int, [_vp, _u32, _u32, _u32, _vp]),
     "ldx_probe_mfma_dev": (_int, [_vp, _u32, _u32, _u32, _int, _vp]),

@@ -305,12 +305,28 @@ __device__ __forceinline__ double max_raw(double a, double b)
     return r;
 }
 
-// true iff the SNP is neither monomorphic nor carries missing codes: a > 0, r > 0, a + r == n
-__device__ __forceinline__ bool fast_ordinary(double fa, double fr, double n)
+// SNP classes of the fast epilogue tiers (round 6: VERDICT r05 item 2 -- panels that are not all complete and polymorphic):
+//   kSnpOrdinary    polymorphic (a > 0, r > 0) with FEW missing codes: m = n - a - r <= r / 8 (m = 0: rounds 1-5's "ordinary").
+//                   Every bound the fast tiers use still holds: with missing codes D' and r^2 are no longer <= 1, but
+//                       |Dn| <= min(a1, a2) (n - max(a1, a2))   for Dn > 0   (n11 <= min(a1, a2))
+//                       |Dn| <= min(a1 a2, (r1 + m1)(r2 + m2))  for Dn < 0   (n11 >= a1 + a2 - n)
+//                   give  D', r^2 <= (1 + m1 / r1)(1 + m2 / r2) <= (9/8)^2 < 1.27  in both sign branches (B = the smaller
+//                   product of calc_ld.py:63-76 in each case), so y = 10^4 value < 12 700 fits the 15-bit cell and the
+//                   kClean variants' dropped guards (y < 10^7, k < 32767, no degenerate operand); a r >= (n - 1) / 2 replaces
+//                   a r >= n - 1 in the r^2 share of the reference's own error (f32_const doubles that term and more);
+//   kSnpDegenerate  a == 0 (whatever is missing), or r == 0 with a == n: calc_ld.py returns the int 0 for BOTH values
+//                   against ANY other SNP, whatever n11 is (:66-69 / :73-76: the bound is 0 or -0.0 -> ZeroDivisionError ->
+//                   d_prime = 0 -> :89-90 r_square = 0) -- and the alt/alt count of such a SNP with any SNP X is known (0,
+//                   resp. a_X), which lets the fp32 tier keep such rows / columns on its common path (f32_row below);
+//   kSnpOdd         everything else (many missing codes; r == 0 with a < n): parks, as every non-ordinary SNP did before.
+constexpr int kSnpOrdinary = 0, kSnpDegenerate = 1, kSnpOdd = 2;
+__device__ __forceinline__ int snp_class(double fa, double fr, double n)
 {
     const double a = __builtin_rint(fa * n), r = __builtin_rint(fr * n);
-    return a > 0.0 && r > 0.0 && a + r == n;
+    if (a == 0.0 || (r == 0.0 && a == n)) return kSnpDegenerate;
+    return (r > 0.0 && 8.0 * (n - a - r) <= r) ? kSnpOrdinary : kSnpOdd;
 }
+__device__ __forceinline__ bool fast_ordinary(double fa, double fr, double n) { return snp_class(fa, fr, n) == kSnpOrdinary; }
 
 __device__ __forceinline__ FastRow fast_row(double fa, double fr, double n)
 {
@@ -394,8 +410,9 @@ __device__ __forceinline__ void ld_multi_fast2(const T (&cnt_scaled)[W], const F
 // VALU instructions per pair instead of ~33 double-rate ones, short enough dependent chains to interleave four pairs
 // -- with a margin test that is wide enough for float32: a lane whose 8 pairs of a step are not ALL provably rounded
 // like the reference hands that step to the fp64 tier above (ld_multi_fast2), through a per-wave queue in LDS, so
-// the common path never branches per pair.  Valid only for ordinary SNPs on both sides (polymorphic, a + r == n:
-// then r^2 <= 1, D' <= 1, B >= 1 and a r >= n - 1, which the error bounds below use); every other SNP parks (f32_row).
+// the common path never branches per pair.  Valid for ordinary SNPs on both sides (snp_class: polymorphic, at most r / 8
+// missing codes: then r^2, D' < 1.27, B >= 1 and a r >= (n - 1) / 2, which the error bounds below use); degenerate SNPs ride
+// along with forced cells, every other SNP parks (f32_row).
 // Round 4 built and measured a leaner form of this arithmetic (integer Dn from accumulators that start at 2^23, floor /
 // fract instead of the magic-number rounding, per-step instead of per-value margins: 22 instead of 28 VALU per pair, 25 %
 // faster stand-alone) -- and it was NOT faster inside the kernel (it parks 0.81 % instead of 0.59 % of the lane-steps, and
@@ -430,27 +447,48 @@ __host__ __device__ inline F32Const f32_const(double n)
 {
     F32Const c;
     c.n = (float)n;
-    const double c0 = 6e-12 * n * n + 1.2e-11 * n * n / (n > 2.0 ? n - 1.0 : 1.0) + 2e-6;
+    // (r^2 share: 1.2e-11 n^2 |Dn| / (a1 r1 a2 r2) with |Dn| <= 1.13 sqrt(a1 r1 a2 r2) and a r >= (n - 1) / 2 for ordinary SNPs
+    // with a few missing codes (snp_class): <= 2.8e-11 n^2 / (n - 1); 4e-11 for slack)
+    const double c0 = 6e-12 * n * n + 4e-11 * n * n / (n > 2.0 ? n - 1.0 : 1.0) + 2e-6;
     c.tol = (float)(0.5 - c0);   // rounds to nearest: the 2e-6 covers that and the last-place effects of the test itself
     return c;
 }
 
 // from the fp64 tier's per-SNP operands (a, 1/a, 1/r as doubles: errors ~1e-16, far below float32's u).
-// A SNP that is not ordinary (monomorphic, or with missing codes: a + r < n) gets all-zero entries: every y_d it takes
-// part in is then exactly 0, the step's  min y_d > 0  test fails and the lane parks the step for the fp64 tier -- the
-// GENERAL variant of it, which knows degenerate operands.  So one such SNP costs its own row / column of cells the slow
-// path, not the whole unit (round 3: one monomorphic SNP among a tile's 128 columns sent every unit of the tile through
-// the fp64 epilogue -- 13 % of the units of the 50 000 x 1008 bench panel for 0.07 % such SNPs).
-__device__ __forceinline__ F32Row f32_row(double a, double ra, double rr, bool ordinary)
+// kSnpOdd gets all-zero entries: every y_d it takes part in is then exactly 0, the step's  min y_d > 0  test fails and the
+// lane parks the step for the fp64 tier -- the GENERAL variant of it, which knows degenerate operands.  So one such SNP
+// costs its own row / column of cells the slow path, not the whole unit.
+// kSnpDegenerate (round 6) stays on the common path.  Its cells are the int-0 code whatever the arithmetic says, so the
+// step loop FORCES them (one v_cndmask per cell under a scalar lane mask, only in units that hold such a SNP:
+// epilogue_f32, kDeg) and the table entries only have to keep the margin test quiet: a fake count A (1 for a == 0, n + 1
+// for a == n) makes  Dn = n c - A1 A2  a NEGATIVE NON-ZERO integer against every other entry -- c is 0 for an all-REF
+// SNP and a_X for an all-ALT one, so Dn = -A_X resp. a_X n - (n + 1) A_X = -a_X (ordinary X), -(n + 1), -(2n + 1) -- the
+// sign picks x = ra, y = rr;  ra = eps, rr = 0, s = 0  give  y_r = 0  and a tiny positive  y_d  (eps_r = 2^-10 against an
+// ordinary column: y_d = a_X eps_r fl(1 / a_X); eps_c = 2^-24 against an ordinary row: 10^4 eps_c; both: <= (2n + 2) 2^-34):
+// both round to 0 with a margin near 0, min y_d > 0 holds, nothing parks.  (30 % monomorphic rows at 50 000 x 1008 -- a
+// sub-panel of the ALL-panel variants -- sent EVERY unit through the fp64 epilogue before: bench.py, other_workloads.)
+__device__ __forceinline__ F32Row f32_row(double a, double ra, double rr, int cls, double n)
 {
-    if (!ordinary) return F32Row{0.0f, 0.0f, 0.0f, 0.0f};
+    if (cls == kSnpOdd) return F32Row{0.0f, 0.0f, 0.0f, 0.0f};
+    if (cls == kSnpDegenerate) return F32Row{a == 0.0 ? 1.0f : (float)(n + 1.0), 0x1p-10f, 0.0f, 0.0f};
     return F32Row{(float)a, (float)(1e4 * ra), (float)(1e4 * rr), (float)(10.0 * __builtin_sqrt(ra * rr))};
 }
 
-__device__ __forceinline__ F32Col f32_col(double a, double ra, double rr, bool ordinary)
+__device__ __forceinline__ F32Col f32_col(double a, double ra, double rr, int cls, double n)
 {
-    if (!ordinary) return F32Col{0.0f, 0.0f, 0.0f, 0.0f};
+    if (cls == kSnpOdd) return F32Col{0.0f, 0.0f, 0.0f, 0.0f};
+    if (cls == kSnpDegenerate) return F32Col{a == 0.0 ? 1.0f : (float)(n + 1.0), 0x1p-24f, 0.0f, 0.0f};
     return F32Col{(float)a, (float)ra, (float)rr, (float)(10.0 * __builtin_sqrt(ra * rr))};
+}
+// a table entry of a kSnpDegenerate SNP (s == 0 marks "not ordinary", ra / ra_s != 0 tells it from kSnpOdd's zeros)
+__device__ __forceinline__ bool f32_entry_degenerate(float ra, float s) { return s == 0.0f && ra != 0.0f; }
+
+// dst = lane's mask bit ? forced : keep, the mask in a scalar register pair (SALU-made: s_or_b64 of a row and a column mask)
+__device__ __forceinline__ uint32_t select_lanes(uint32_t keep, uint32_t forced, uint64_t mask)
+{
+    uint32_t o;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(o) : "v"(keep), "v"(forced), "s"(mask));
+    return o;
 }
 
 // float32 nearest to k / 10^4 for an integer-valued float k < 2^15: quotient by the reciprocal plus one exact

@@ -636,7 +636,8 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 if (new_tile && tid < kSlab) {
                     const uint32_t j = t * kSlab + tid;
                     const FastCol c = fast_col(fa[j], fr[j], n);
-                    const bool odd = !fast_ordinary(fa[j], fr[j], n);
+                    const int ccls = snp_class(fa[j], fr[j], n);
+                    const bool odd = ccls != kSnpOrdinary;   // (degenerate SNPs included: the fp64 tiers then run their general variant)
                     if (lane == 0) cols_odd[wave] = 0u;
                     if (__any(odd) && lane == 0) cols_odd[wave] = 1u;
                     typedef double d2 __attribute__((ext_vector_type(2)));
@@ -645,7 +646,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                     dst[1] = d2{c.rr, c.rq};
                     if (kArea) dst[2] = j < n_snps ? d2{(double)aa.pos[j], (double)(aa.is_query ? aa.is_query[j] : (uint8_t)1)} : d2{0.0, 0.0};
                     if constexpr (kF32Tier) {
-                        const F32Col c32 = f32_col(c.a, c.ra, c.rr, !odd);
+                        const F32Col c32 = f32_col(c.a, c.ra, c.rr, ccls, n);
                         *reinterpret_cast<v4f *>(ctab32 + tid * 4u) = v4f{c32.a, c32.ra, c32.rr, c32.s};
                     }
                     if constexpr (kBandF32) {   // the band's float32 screen (area_epilogue): a = ah + al, and the column's share of
@@ -661,8 +662,8 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 }
                 const uint32_t i = row0 + (MM == 1 ? l32 : lane);   // a half-height unit has 32 rows: stay inside the padded vectors
                 const FastRow r = fast_row(fa[i], fr[i], n);
-                const bool row_ordinary = fast_ordinary(fa[i], fr[i], n);
-                rows_ordinary = __all(row_ordinary);
+                const int rcls = snp_class(fa[i], fr[i], n);
+                rows_ordinary = __all(rcls == kSnpOrdinary);
                 typedef double d2 __attribute__((ext_vector_type(2)));
                 d2 *dst = reinterpret_cast<d2 *>(rstat + (lane < (kArea ? kRows64 : kStatRows) ? lane : 0u) * kStat);
                 if (lane < (kArea ? kRows64 : kStatRows)) {
@@ -670,7 +671,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                     dst[1] = d2{r.rr, r.rq_s};
                 }
                 if constexpr (kF32Tier) {   // (a half-height unit's lanes 32-63 repeat rows 0-31 into slots nobody reads)
-                    const F32Row r32 = f32_row(r.a_s * 1e-4, r.ra, r.rr, row_ordinary);   // 1e4 a / 1e4: exact (a < 2^32)
+                    const F32Row r32 = f32_row(r.a_s * 1e-4, r.ra, r.rr, rcls, n);   // 1e4 a / 1e4: exact (a < 2^32)
                     *reinterpret_cast<v4f *>(rtab32 + lane * 4u) = v4f{r32.a, r32.ra_s, r32.rr_s, r32.s};
                 }
                 if constexpr (kBandF32) {   // {a, s1 = 10 / sqrt(a r)}; 0 for a count of 0 (such a row is never a candidate)
@@ -1011,13 +1012,28 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                     const v4f v = *reinterpret_cast<const v4f *>(ct + 32u * tt * 4u);
                     cols[tt] = F32Col{v.x, v.y, v.z, v.w};
                 }
+                // Degenerate SNPs of this unit (ldx_common.h, snp_class / f32_row): lane masks, all scalar.  colmask[tt] = lanes
+                // whose column of tile tt is degenerate (from the table entries this lane just read); rdeg = bit per row of the
+                // wave's 64 (lane l reads row l's entry once).  A unit without any runs the loop it always ran.
+                uint64_t colmask[4], rdeg;
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) colmask[tt] = __builtin_amdgcn_ballot_w64(f32_entry_degenerate(cols[tt].ra, cols[tt].s));
+                {
+                    const v4f rv = *reinterpret_cast<const v4f *>(rtab32 + (MM == 1 ? l32e : ln) * 4u);
+                    rdeg = __builtin_amdgcn_ballot_w64(f32_entry_degenerate(rv.y, rv.w));
+                }
+                const bool any_deg = (rdeg | colmask[0] | colmask[1] | colmask[2] | colmask[3]) != 0ull;   // wave-uniform
                 float cal[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // n > 4096: the columns' counts split (ldx_common.h, f32_split_a): a = ah + al
                 if (!f32_small_n((double)fc32.n)) {
 #pragma unroll
                     for (int tt = 0; tt < 4; ++tt) f32_split_a(cols[tt].a, cols[tt].a, cal[tt]);
                 }
-                // the sixteen steps, in two instantiations: n <= 4096 needs no error term for the product a1 a2 (ldx_common.h)
-                auto steps = [&](auto small_c) -> bool {
+                // the sixteen steps, in four instantiations: n <= 4096 needs no error term for the product a1 a2 (ldx_common.h);
+                // kDeg forces the cells of degenerate rows / columns to the int-0 code (one v_cndmask per cell)
+                auto steps = [&](auto small_c, auto deg_c) -> bool {
+                constexpr bool kDeg = decltype(deg_c)::value;
+                uint32_t forced = sizeof(Cell) == 4 ? ((uint32_t)LDX_K16_INT0 << 16 | LDX_K16_INT0) : 0x80000000u;   // int 0, int 0
+                if constexpr (kDeg) asm volatile("" : "+v"(forced));   // (a vector register: VOP3 takes no literal on gfx9)
                 // LDX_STEP_UNROLL steps per trip of the loop (1, 2, 4, 8 or 16; the rows of a step are (e & 3) + 8 (e >> 2) + 32 m:
                 // unrolled by 4 the row inside its group of eight is static -- LDS and store offsets become immediates, the
                 // scalar address arithmetic happens once per four steps --, unrolled by 16 the accumulator index is static too)
@@ -1061,6 +1077,21 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                             r4[tt] = rows[g];
                         }
                         ld_multi_f32<4, Cell, decltype(small_c)::value, !decltype(small_c)::value>(c4, fc32, r4, cols, o4, wmax, ymin, cal);
+                        if constexpr (kDeg) {   // this step's two rows of tile g: lanes 0-31 hold row ri, lanes 32-63 row ri + 4
+                            const uint32_t ri0 = 32u * g + (e & 3) + 8u * (e >> 2);
+                            const uint64_t rowmask = (((rdeg >> ri0) & 1ull) ? 0x00000000FFFFFFFFull : 0ull) |
+                                                     (((rdeg >> (ri0 + 4u)) & 1ull) ? 0xFFFFFFFF00000000ull : 0ull);
+#pragma unroll
+                            for (int tt = 0; tt < 4; ++tt) {
+                                const uint64_t m = rowmask | colmask[tt];
+                                if constexpr (sizeof(Cell) == 4) {
+                                    o4[tt] = __builtin_bit_cast(Cell, select_lanes(__builtin_bit_cast(uint32_t, o4[tt]), forced, m));
+                                } else {
+                                    const v2u w = __builtin_bit_cast(v2u, o4[tt]);
+                                    o4[tt] = __builtin_bit_cast(Cell, v2u{select_lanes(w.x, forced, m), select_lanes(w.y, forced, m)});
+                                }
+                            }
+                        }
 #pragma unroll
                         for (int tt = 0; tt < 4; ++tt) cell[g * 4 + tt] = o4[tt];
                     }
@@ -1110,7 +1141,10 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
 #endif
                     return true;
                 };
-                if (!(f32_small_n((double)fc32.n) ? steps(std::true_type{}) : steps(std::false_type{}))) return false;
+                const bool small_n = f32_small_n((double)fc32.n);
+                const bool done = any_deg ? (small_n ? steps(std::true_type{}, std::true_type{}) : steps(std::false_type{}, std::true_type{}))
+                                          : (small_n ? steps(std::true_type{}, std::false_type{}) : steps(std::false_type{}, std::false_type{}));
+                if (!done) return false;
                 // ---- the parked steps: fp64 tier ----
                 LDX_COUNT(0, 1);
                 LDX_COUNT(1, qn);

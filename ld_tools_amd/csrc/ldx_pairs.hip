@@ -201,8 +201,8 @@ __device__ inline Cell all_tiers(double n, double rn, uint32_t c11, double fa1, 
             same = same && same_cell(g_[0], res);
             // the fp32 first tier of the FP4 kernel: whenever it calls a pair sure, its cell must be the mirror's
             const F32Const f32k = f32_const(n);
-            const F32Row r32[1] = {f32_row(fr_[0].a_s * 1e-4, fr_[0].ra, fr_[0].rr, true)};
-            const F32Col c32[1] = {f32_col(fc_[0].a, fc_[0].ra, fc_[0].rr, true)};
+            const F32Row r32[1] = {f32_row(fr_[0].a_s * 1e-4, fr_[0].ra, fr_[0].rr, kSnpOrdinary, n)};
+            const F32Col c32[1] = {f32_col(fc_[0].a, fc_[0].ra, fc_[0].rr, kSnpOrdinary, n)};
             Cell h_[1];
             float wmax = 0.0f, ymin = 1.0f;
             if (f32_small_n(n)) ld_multi_f32<1, Cell, true>(cnt_, f32k, r32, c32, h_, wmax, ymin);   // the variant the kernel picks for this n

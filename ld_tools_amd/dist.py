@@ -56,6 +56,27 @@ def unit_partition(n_snps: int, world: int) -> List[Tuple[int, int]]:
     return [(total * r // world, total * (r + 1) // world) for r in range(world)]
 
 
+def pairs_in_units(n_snps: int, u0: int, u1: int) -> int:
+    """Number of valid cells (row > col, row < n_snps) -- i.e. SNP pairs -- in units [u0, u1): a rank's share of the work
+    (bench.py prints it per rank; equal UNIT counts are equal pair counts up to the diagonal and the padding)."""
+    import numpy as np
+
+    t_count = (n_snps + SLAB - 1) // SLAB
+    G = t_count * (SLAB // GROUP)
+    total = 0
+    for t in range(t_count):
+        base = t * G - 8 * t * (t - 1)
+        nxt = (t + 1) * G - 8 * (t + 1) * t
+        a, b = max(u0, base), min(u1, nxt)
+        if a >= b:
+            continue
+        g = np.arange(a, b, dtype=np.int64) - base + 16 * t
+        r = (g[:, None] * GROUP + np.arange(GROUP, dtype=np.int64)[None, :]).ravel()
+        r = r[r < n_snps]
+        total += int(np.clip(r - t * SLAB, 0, SLAB).sum())
+    return total
+
+
 def unit_cells(n_snps: int, u0: int, u1: int):
     """(rows, cols) int64 arrays of the valid cells (row > col, row < n_snps) of units [u0, u1)."""
     import numpy as np

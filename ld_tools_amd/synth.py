@@ -9,6 +9,12 @@ numpy generator below and ldx_synth_codes_dev produce the same codes bit for bit
     copy(i, h)      = i % block_len != 0 and key(seed+1, i, h) < rho * 2^64
     g[i][h]         = g[i-1][h] if copy else key(seed+2, i, h) < p_i * 2^64
     code[i][h]      = 2 if key(seed+3, i, h) < miss * 2^64 else g[i][h]
+
+Panels that are not all "ordinary" (round 6; a sub-panel of the ALL-panel variants holds many SNPs that are monomorphic
+in it, and the reference maps those to the int 0: calc_ld.py:55-76,89-90):
+    miss applies only to rows with key(seed+6, i, 2^64-1) < miss_rows * 2^64   (miss_rows = 1: every row)
+    a row with key(seed+4, i, 2^64-1) < mono * 2^64 is monomorphic: every code 0, or every code 1 when
+    key(seed+5, i, 2^64-1) & 7 == 0; the LD chain underneath is not disturbed
 """
 from __future__ import annotations
 
@@ -62,7 +68,8 @@ def snp_thresholds(seed: int, first_snp: int, count: int, n_hap: int) -> np.ndar
 
 
 def synth_codes_host(n_snps: int, n_hap: int, seed: int = BENCH_SEED, miss: float = 0.0,
-                     block_len: int = BLOCK_LEN, rho: float = RHO, snp_offset: int = 0) -> np.ndarray:
+                     block_len: int = BLOCK_LEN, rho: float = RHO, snp_offset: int = 0, mono: float = 0.0,
+                     miss_rows: float = 1.0) -> np.ndarray:
     """int8 [n_snps][n_hap] codes of global SNPs [snp_offset, snp_offset + n_snps) (numpy)."""
     first_block = snp_offset // block_len
     last_block = (snp_offset + n_snps - 1) // block_len
@@ -84,14 +91,22 @@ def synth_codes_host(n_snps: int, n_hap: int, seed: int = BENCH_SEED, miss: floa
             g = np.where(copy, g, fresh)
         code = g
         if miss > 0.0:
-            code = np.where(key64(seed + 3, gi, h) < miss_thr, np.int8(2), g)
+            hit = key64(seed + 3, gi, h) < miss_thr
+            if miss_rows < 1.0:
+                hit = hit & (key64(seed + 6, gi, np.uint64(M64)) < np.uint64(prob_to_thr(miss_rows)))
+            code = np.where(hit, np.int8(2), g)
+        if mono > 0.0:
+            is_mono = key64(seed + 4, gi, np.uint64(M64)) < np.uint64(prob_to_thr(mono))
+            all_alt = (key64(seed + 5, gi, np.uint64(M64)) & np.uint64(7)) == np.uint64(0)
+            code = np.where(is_mono, np.where(all_alt, np.int8(1), np.int8(0)), code)
         out[k::block_len] = code
     lo = snp_offset - base
     return np.ascontiguousarray(out[lo:lo + n_snps])
 
 
 def synth_codes_device(n_snps: int, n_hap: int, seed: int = BENCH_SEED, miss: float = 0.0,
-                       block_len: int = BLOCK_LEN, rho: float = RHO, snp_offset: int = 0, device=None):
+                       block_len: int = BLOCK_LEN, rho: float = RHO, snp_offset: int = 0, device=None,
+                       mono: float = 0.0, miss_rows: float = 1.0):
     """Same codes generated on the GPU (torch int8 tensor [n_snps][ld], ld = n_hap rounded up to 16)."""
     import torch
 
@@ -106,9 +121,10 @@ def synth_codes_device(n_snps: int, n_hap: int, seed: int = BENCH_SEED, miss: fl
     thr_d = torch.from_numpy(thr.view(np.int64)).to(dev)
     ld = (n_hap + 15) // 16 * 16
     codes = torch.empty((n_snps, ld), dtype=torch.int8, device=dev)
-    check(lib.ldx_synth_codes_dev(codes.data_ptr(), n_snps, n_hap, ld, seed & M64, thr_d.data_ptr(),
-                                  prob_to_thr(rho), block_len, prob_to_thr(miss), snp_offset, _stream_ptr()),
-          "ldx_synth_codes_dev")
+    check(lib.ldx_synth_codes_ex_dev(codes.data_ptr(), n_snps, n_hap, ld, seed & M64, thr_d.data_ptr(),
+                                     prob_to_thr(rho), block_len, prob_to_thr(miss), snp_offset, prob_to_thr(mono),
+                                     M64 if miss_rows >= 1.0 else prob_to_thr(miss_rows), _stream_ptr()),
+          "ldx_synth_codes_ex_dev")
     return codes[:, :n_hap]
 
 

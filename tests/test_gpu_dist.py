@@ -50,6 +50,12 @@ def test_bench_launches_its_own_ranks():
     assert rec["config"]["workload"] == "ld_triangle 3000x5008" and rec["value"] > 0
     assert rec["config"]["single_gpu_same_workload"]["pairs_per_s"] > 0
     assert rec["roofline"]["kernel_ms"] >= rec["roofline"]["kernel_ms_min_rank"] > 0
+    # SURVEY 8(d) / VERDICT r05 item 4: the headline is the median of seven timed regions, all of them on the line
+    assert len(rec["ms_per_step_runs"]) == 7 and rec["ms_per_step_min"] == min(rec["ms_per_step_runs"])
+    assert rec["ms_per_step_min"] <= rec["ms_per_step"] and rec["ms_per_step"] == sorted(rec["ms_per_step_runs"])[3]
+    # one record per rank
+    assert [r_["rank"] for r_ in rec["per_rank"]] == [0, 1] and all(r_["kernel_ms"] > 0 and r_["pairs"] > 0 for r_ in rec["per_rank"])
+    assert sum(r_["pairs"] for r_ in rec["per_rank"]) == 3000 * 2999 // 2
 
 
 @pytest.mark.gpu
@@ -87,9 +93,15 @@ def test_bench_other_workloads_are_verified():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     legs = rec["other_workloads"]
-    for key in ("ld_triangle 6000x1008", "ld_triangle 12000x5008", "ld_area 12000 +-500kb r2>=0.8"):
+    for key in ("ld_triangle 6000x1008", "ld_triangle 12000x5008", "ld_area 12000 +-500kb r2>=0.8",
+                "ld_triangle 6000x1008, 30 % of rows monomorphic", "ld_triangle 5000x5008, 0.1 % code-2 in 20 % of rows"):
         assert "error" not in legs[key], legs[key]
         assert legs[key]["results_equal"] is True, (key, legs[key])
+    mono = legs["ld_triangle 6000x1008, 30 % of rows monomorphic"]
+    assert 0.25 * 6000 < mono["non_ordinary_snps"]["acnt_zero_or_full"] < 0.35 * 6000 and mono["clean_twin_ms"] > 0
+    assert 0.1 * 5000 < legs["ld_triangle 5000x5008, 0.1 % code-2 in 20 % of rows"]["non_ordinary_snps"]["with_missing_codes"] < 0.3 * 5000
+    assert len(rec["ms_per_step_runs"]) == 7 and rec["ms_per_step_min"] <= rec["ms_per_step"]
+    assert legs["ld_triangle 6000x1008"]["ms_min"] <= legs["ld_triangle 6000x1008"]["ms"]
     assert legs["ld_triangle 12000x5008"]["roofline"]["kernel_ms"] > 0
     assert "unit ranges [2, 7]" in legs["ld_triangle 12000x5008"]["verified_against"]
     assert rec["other_paths"]["two_streams"]["results_equal"] is True
@@ -129,3 +141,14 @@ def test_bench_four_ranks_one_card_configs3():
     assert rec["retried"] is False and rec["first_attempt_rc"] == 0
     assert "overlapped" in cfg["exchange"] and "popcount kernel" in cfg["launch"]
     assert cfg["single_gpu_same_workload"]["pairs_per_s"] > 0 and rec["value"] > 0
+    # per rank its kernel time, the exposed part of its exchange and its share of the work.  The split is by
+    # UNITS (8 rows x 128 columns: what the kernel's time is proportional to -- a unit on the diagonal or in the padding costs
+    # what a full one costs), equal to within one unit; in PAIRS the last rank, which owns the short last tiles with their
+    # larger share of diagonal units, therefore gets ~0.5 % fewer.
+    pr = rec["per_rank"]
+    assert [x["rank"] for x in pr] == [0, 1, 2, 3] and len(rec["ms_per_step_runs"]) == 7
+    units = [x["units"] for x in pr]
+    assert max(units) - min(units) <= 1
+    pairs = [x["pairs"] for x in pr]
+    assert sum(pairs) == 100000 * 99999 // 2 and max(pairs) / min(pairs) - 1.0 < 0.006, pairs
+    assert all(x["kernel_ms"] > 0 and x["exchange_ms_per_step"] is not None for x in pr)

@@ -198,6 +198,18 @@ def test_synth_device_equals_host(gpu):
         dev = synth.synth_codes_device(n, h, seed=seed, miss=miss, snp_offset=off).cpu().numpy()
         host = synth.synth_codes_host(n, h, seed=seed, miss=miss, snp_offset=off)
         assert np.array_equal(dev, host), (n, h, seed)
+    # round 6: panels with monomorphic rows and with missing codes confined to a share of the rows (bench.py's odd-panel legs)
+    for (n, h, seed, miss, off, mono, mrows) in [(200, 1008, 20261003, 0.0, 0, 0.3, 1.0), (160, 517, 5, 0.001, 37, 0.0, 0.2),
+                                                (130, 300, 9, 0.05, 64, 0.25, 0.5)]:
+        dev = synth.synth_codes_device(n, h, seed=seed, miss=miss, snp_offset=off, mono=mono, miss_rows=mrows).cpu().numpy()
+        host = synth.synth_codes_host(n, h, seed=seed, miss=miss, snp_offset=off, mono=mono, miss_rows=mrows)
+        assert np.array_equal(dev, host), (n, h, seed, mono, mrows)
+        flat = (dev == dev[:, :1]).all(axis=1)
+        if mono:
+            assert 0.1 * n < flat.sum() < 0.5 * n, flat.sum()
+        if miss and mrows < 1.0:
+            with_miss = (dev == 2).any(axis=1)
+            assert 0 < with_miss.sum() < 0.8 * n
 
 
 # ------------------------------------------------------------------ counts (bit-exact contract)
@@ -283,7 +295,9 @@ def test_epilogue_random_tuples_at_panel_sizes(gpu, n):
     rnd, flags, k = rnd.cpu().numpy(), flags.cpu().numpy(), k.cpu().numpy()
     # the fp32 tier keeps most ordinary pairs (the rest go to the fp64 tier); whenever it keeps one its cell equals the
     # others' (checked in the kernel: a disagreement poisons the cell)
-    ordinary = (arrs[1] > 0) & (arrs[2] > 0) & (arrs[3] > 0) & (arrs[4] > 0) & (arrs[1] + arrs[2] == n) & (arrs[3] + arrs[4] == n)
+    # (ordinary since round 6, csrc/ldx_common.h snp_class: polymorphic with at most r / 8 missing codes)
+    a1_, r1_, a2_, r2_ = (x.astype(np.int64) for x in arrs[1:])
+    ordinary = (a1_ > 0) & (r1_ > 0) & (a2_ > 0) & (r2_ > 0) & (8 * (n - a1_ - r1_) <= r1_) & (8 * (n - a2_ - r2_) <= r2_)
     sure32 = sure32.cpu().numpy()
     assert not sure32[~ordinary].any() and sure32[ordinary].mean() > 0.9, sure32[ordinary].mean()
     o_rsq_raw, o_dp_raw, o_rsq, o_dp, o_flags = c_oracle.ld_from_counts_v(n, *arrs, libm_pow=True)
@@ -298,6 +312,49 @@ def test_epilogue_random_tuples_at_panel_sizes(gpu, n):
     raw = raw.cpu().numpy()
     assert np.array_equal(raw[:, 1], o_dp_raw)                                # unrounded D': bit-identical
     assert np.max(np.abs(raw[:, 0] - o_rsq_raw) / np.maximum(1.0, np.abs(o_rsq_raw))) <= 1e-6
+
+
+@pytest.mark.parametrize("n", [5008, 1008, 10240, 4096])
+def test_epilogue_tuples_with_a_few_missing_codes(gpu, n):
+    """Round 6: the fast tiers take polymorphic SNPs with a FEW missing codes (m = n - a - r <= r / 8; csrc/ldx_common.h,
+    snp_class) on their common path -- D' and r^2 may then exceed 1 (< 1.27), which the bounds allow for.  Two million such
+    tuples -- every feasible kind of n11: the whole range [max(0, a1 + a2 - n), min(a1, a2)], its two ends, and |Dn| small --
+    through every tier (ld_from_counts poisons a cell on which two tiers disagree) against the C restatement of
+    calc_ld.py:33-97; the fp32 tier must keep most of them."""
+    from ld_tools_amd import ld_from_counts
+    from oracle import c_oracle
+
+    rng = np.random.RandomState(n + 1)
+    m = 2_000_000
+    kind = rng.randint(0, 4, m)
+
+    def snp():
+        miss = (rng.rand(m) ** 3 * (n // 9)).astype(np.int64)                  # mostly a handful, up to ~n / 9
+        a = 1 + (np.sin(np.pi / 2 * rng.rand(m)) ** 2 * (n - miss - 2)).astype(np.int64)
+        r = n - miss - a
+        ok = (r > 0) & (8 * miss <= r)
+        miss = np.where(ok, miss, 0)
+        a = np.where(ok, a, np.clip(a, 1, n - 1))
+        return a, n - miss - a
+
+    a1, r1 = snp()
+    a2, r2 = snp()
+    assert ((r1 > 0) & (r2 > 0) & (8 * (n - a1 - r1) <= r1) & (8 * (n - a2 - r2) <= r2)).all()
+    lo, hi = np.maximum(0, a1 + a2 - n), np.minimum(a1, a2)
+    indep = np.rint(a1.astype(np.float64) * a2 / n).astype(np.int64)
+    n11 = np.where(kind == 0, lo + (rng.rand(m) * (hi - lo + 1)).astype(np.int64),
+                   np.where(kind == 1, indep + rng.randint(-2, 3, m), np.where(kind == 2, lo, hi)))
+    n11 = np.clip(n11, lo, hi)
+    arrs = [x.astype(np.uint32) for x in (n11, a1, r1, a2, r2)]
+    raw, rnd, flags, k, k16, sure32 = ld_from_counts(n, *arrs, full=True)
+    rnd, flags, k, sure32 = rnd.cpu().numpy(), flags.cpu().numpy(), k.cpu().numpy(), sure32.cpu().numpy()
+    assert sure32.mean() > 0.9, sure32.mean()
+    o_rsq_raw, o_dp_raw, o_rsq, o_dp, o_flags = c_oracle.ld_from_counts_v(n, *arrs, libm_pow=True)
+    assert np.array_equal(flags, o_flags)
+    assert np.array_equal(k[:, 0] / 1e4, o_rsq) and np.array_equal(k[:, 1] / 1e4, o_dp)
+    check_cells(k, o_flags, rnd, k16.cpu().numpy(), n)
+    assert max(o_rsq.max(), o_dp.max()) < 1.27 and max(o_rsq.max(), o_dp.max()) > 1.0      # beyond 1, inside the bound
+    assert np.array_equal(raw.cpu().numpy()[:, 1], o_dp_raw)
 
 
 def test_epilogue_kat(gpu, kat):
@@ -637,6 +694,63 @@ def test_config4_triangle_50k_x_1008(gpu):
     assert int(ref.n11.to(torch.int64).sum().item()) == int((colsum * (colsum - 1) // 2).sum())
 
 
+def oracle_rows_against_k16(o, res, k16, bands, workers=8):
+    """oracle_rows_against_cells for the PRODUCT variant's 4-byte cells (no n11 side output: the fp32 tier and its fallbacks):
+    k of r^2 and D' and the int-0 marks of every cell (row > col) of the rows in `bands` against the C oracle."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(band):
+        r0, r1 = band
+        t = o.triangle_band(r0, r1, libm_pow=True, want=("rsq_rnd", "dp_rnd", "flags"))
+        counts = np.arange(r0, r1, dtype=np.int64)
+        rows = np.repeat(counts, counts)
+        cols = np.concatenate([np.arange(i, dtype=np.int64) for i in range(r0, r1)])
+        u = k16[res.cell_index(rows, cols)].astype(np.int64)
+        rb = rows - r0
+        fl = t["flags"][rb, cols]
+        assert not (u == 0x7FFF).any(), ("escape cell", band)
+        want_r = np.where((fl & 2) != 0, 0x8000, np.rint(t["rsq_rnd"][rb, cols] * 1e4).astype(np.int64))
+        want_d = np.where((fl & 1) != 0, 0x8000, np.rint(t["dp_rnd"][rb, cols] * 1e4).astype(np.int64))
+        assert np.array_equal(u[:, 0], want_r), ("r_square", band)
+        assert np.array_equal(u[:, 1], want_d), ("d_prime", band)
+        return len(rows)
+
+    bands = [b for b in bands if b[1] > max(b[0], 1)]
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        return sum(pool.map(one, bands))
+
+
+@pytest.mark.parametrize("n,h", [(10000, 5008), (50000, 1008)])
+def test_panels_with_monomorphic_and_missing_code_snps_at_bench_sizes(gpu, n, h):
+    """panels that are not all ordinary, at configs[1]'s and configs[4]'s sizes -- 30 % of the SNPs
+    monomorphic (what a sub-panel of the ALL-panel variants holds) AND 0.1 % code 2 in 20 % of the rows.  The product variant
+    of the FP4 kernel (fp32 tier with forced int-0 cells for the degenerate rows / columns, a few missing codes on the common
+    path) against the popcount kernel, every cell, both formats; and >= 5 % of the rows, all their cells, against the C oracle."""
+    import torch
+    from ld_tools_amd import PackedPanel, ld_triangle, synth
+    from oracle import c_oracle
+
+    codes_d = synth.synth_codes_device(n, h, seed=synth.BENCH_SEED, miss=0.001, mono=0.3, miss_rows=0.2)
+    p = PackedPanel.from_codes(codes_d)
+    got = ld_triangle(p, fmt="k16", path="fp4")
+    want = ld_triangle(p, fmt="k16", path="popcount")
+    assert torch.equal(got.k16, want.k16)
+    del want
+    if n <= 10000:
+        a, b = ld_triangle(p, fmt="ld32", path="fp4"), ld_triangle(p, fmt="ld32", path="popcount")
+        assert torch.equal(a.ld32.view(torch.int32), b.ld32.view(torch.int32))
+        del a, b
+    codes = codes_d.cpu().numpy()
+    flat = (codes == codes[:, :1]).all(axis=1)
+    assert 0.25 * n < flat.sum() < 0.35 * n and 0.1 * n < (codes == 2).any(axis=1).sum() < 0.25 * n
+    o = c_oracle.Panel(codes)
+    k16 = got.k16.cpu().numpy().view(np.uint16)
+    step = 500
+    bands = [(1, 20), (n - 4, n)] + [(r, min(r + 27, n)) for r in range(20, n, step)]
+    assert sum(b[1] - b[0] for b in bands) >= 0.05 * n
+    assert oracle_rows_against_k16(o, got, k16, bands) >= 0.05 * n * (n - 1) / 2 * 0.9
+
+
 def test_config2_area_100k_500kb(gpu):
     """BASELINE configs[2]: ld_area over a 100 000-SNP chromosome (positions 1 + 500 i: +-500 kb = +-1000 neighbours), every
     SNP a query, rounded r^2 >= 0.8.  The matrix-pipe band (FP4 and int8) and the popcount scan return the same hits;
@@ -743,8 +857,9 @@ def test_triangle_half_height_tickets_agree(gpu, path):
 
 
 def test_fp32_tier_parks_the_rows_and_columns_of_odd_snps(gpu):
-    """Round 4: a SNP that is not ordinary (monomorphic ALT / REF, all missing, some missing codes) parks its own row /
-    column of lane-steps in the fp32 tier instead of sending the whole unit to the fp64 epilogue.  Panels with one, a few
+    """Round 4: a SNP that is not ordinary parks its own row / column of lane-steps in the fp32 tier instead of sending the whole
+    unit to the fp64 epilogue; round 6: monomorphic ALT / REF and all-missing SNPs do not even park (their cells are forced to the
+    int-0 code on the common path) and SNPs with a few missing codes are ordinary; many missing codes still park.  Panels with one, a few
     and MANY such SNPs per tile (the last overflows the per-wave queue: the unit is redone whole) through the product
     variant of the FP4 kernel -- interior units only exist from ~400 SNPs on -- against the popcount kernel, both cell
     formats, and a band of rows against the C oracle."""
@@ -758,15 +873,20 @@ def test_fp32_tier_parks_the_rows_and_columns_of_odd_snps(gpu):
         codes = synth.synth_codes_host(n, h, seed=5 + n_odd, miss=0.0)
         rows = rng.choice(n, size=n_odd, replace=False)
         for k, r in enumerate(rows):
-            kind = k % 4
+            kind = k % 6
             if kind == 0:
-                codes[r] = 0                                   # monomorphic REF
+                codes[r] = 0                                   # monomorphic REF   (degenerate: forced cells, round 6)
             elif kind == 1:
-                codes[r] = 1                                   # monomorphic ALT
+                codes[r] = 1                                   # monomorphic ALT   (degenerate)
             elif kind == 2:
-                codes[r, ::7] = 2                              # missing codes: a + r < n
+                codes[r, ::7] = 2                              # many missing codes: a + r < n   (odd: parks)
+            elif kind == 3:
+                codes[r] = 2                                   # nothing but missing codes   (a == 0: degenerate)
+            elif kind == 4:
+                codes[r, 5:9] = 2                              # a few missing codes   (ordinary since round 6)
             else:
-                codes[r] = 2                                   # nothing but missing codes
+                codes[r] = 1
+                codes[r, ::3] = 2                              # no REF allele but a < n   (odd: n11 is not determined)
         p = PackedPanel.from_codes(codes)
         for fmt in ("k16", "ld32"):
             got = ld_triangle(p, fmt=fmt, path="fp4")          # no side outputs: the fp32 tier + its fallbacks
