@@ -483,12 +483,15 @@ __device__ __forceinline__ F32Col f32_col(double a, double ra, double rr, int cl
 // a table entry of a kSnpDegenerate SNP (s == 0 marks "not ordinary", ra / ra_s != 0 tells it from kSnpOdd's zeros)
 __device__ __forceinline__ bool f32_entry_degenerate(float ra, float s) { return s == 0.0f && ra != 0.0f; }
 
-// dst = lane's mask bit ? forced : keep, the mask in a scalar register pair (SALU-made: s_or_b64 of a row and a column mask)
+// dst = lane's mask bit ? forced : keep, the mask a wave-uniform 64-bit value (SALU-made: s_or_b64 of a row and a column mask).
+// __builtin_amdgcn_inverse_ballot_w64 hands the scalar mask to the compiler AS a lane mask: it emits  s_or_b64 vcc, .. ;
+// v_cndmask_b32 dst, keep, forced, vcc  -- one vector instruction -- and keeps the hazard bookkeeping.  (The first form of
+// this, an inline-asm  v_cndmask_b32_e64 dst, keep, forced, s[mask]  right behind the s_or_b64, returned ZERO in lanes 12-15
+// / 28-31 / 44-47 / 60-63 of the first select behind a ds_read-written destination in some steps: found by
+// tools/gpu_diff6.py; a plain C++  (mask >> lane) & 1  costs four vector instructions per cell.)
 __device__ __forceinline__ uint32_t select_lanes(uint32_t keep, uint32_t forced, uint64_t mask)
 {
-    uint32_t o;
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(o) : "v"(keep), "v"(forced), "s"(mask));
-    return o;
+    return __builtin_amdgcn_inverse_ballot_w64(mask) ? forced : keep;
 }
 
 // float32 nearest to k / 10^4 for an integer-valued float k < 2^15: quotient by the reciprocal plus one exact

@@ -1022,7 +1022,11 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                     const v4f rv = *reinterpret_cast<const v4f *>(rtab32 + (MM == 1 ? l32e : ln) * 4u);
                     rdeg = __builtin_amdgcn_ballot_w64(f32_entry_degenerate(rv.y, rv.w));
                 }
+#ifdef LDX_AB_NODEGSEL   // tuning: never force (the cells of degenerate SNPs come out as 0 / 0: wrong by design)
+                const bool any_deg = false;
+#else
                 const bool any_deg = (rdeg | colmask[0] | colmask[1] | colmask[2] | colmask[3]) != 0ull;   // wave-uniform
+#endif
                 float cal[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // n > 4096: the columns' counts split (ldx_common.h, f32_split_a): a = ah + al
                 if (!f32_small_n((double)fc32.n)) {
 #pragma unroll
@@ -1032,8 +1036,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 // kDeg forces the cells of degenerate rows / columns to the int-0 code (one v_cndmask per cell)
                 auto steps = [&](auto small_c, auto deg_c) -> bool {
                 constexpr bool kDeg = decltype(deg_c)::value;
-                uint32_t forced = sizeof(Cell) == 4 ? ((uint32_t)LDX_K16_INT0 << 16 | LDX_K16_INT0) : 0x80000000u;   // int 0, int 0
-                if constexpr (kDeg) asm volatile("" : "+v"(forced));   // (a vector register: VOP3 takes no literal on gfx9)
+                const uint32_t forced = sizeof(Cell) == 4 ? ((uint32_t)LDX_K16_INT0 << 16 | LDX_K16_INT0) : 0x80000000u;   // int 0, int 0
                 // LDX_STEP_UNROLL steps per trip of the loop (1, 2, 4, 8 or 16; the rows of a step are (e & 3) + 8 (e >> 2) + 32 m:
                 // unrolled by 4 the row inside its group of eight is static -- LDS and store offsets become immediates, the
                 // scalar address arithmetic happens once per four steps --, unrolled by 16 the accumulator index is static too)
