@@ -323,6 +323,9 @@ constexpr int kSnpOrdinary = 0, kSnpDegenerate = 1, kSnpOdd = 2;
 __device__ __forceinline__ int snp_class(double fa, double fr, double n)
 {
     const double a = __builtin_rint(fa * n), r = __builtin_rint(fr * n);
+#ifdef LDX_AB_R5CLASS   // tuning: rounds 1-5's rule -- ordinary iff polymorphic and complete, everything else parks
+    return (a > 0.0 && r > 0.0 && a + r == n) ? kSnpOrdinary : kSnpOdd;
+#endif
     if (a == 0.0 || (r == 0.0 && a == n)) return kSnpDegenerate;
     return (r > 0.0 && 8.0 * (n - a - r) <= r) ? kSnpOrdinary : kSnpOdd;
 }

@@ -64,6 +64,14 @@ __device__ __forceinline__ void gload16x2_s(v4u &dst0, v4u &dst1, uint32_t voff,
     asm volatile("s_mov_b64 %2, %4\n\tglobal_load_dwordx4 %0, %3, %2\n\tglobal_load_dwordx4 %1, %3, %2 offset:512"
                  : "=&v"(dst0), "=&v"(dst1), "=&s"(t) : "v"(voff), "s"(sbase));   // early-clobber: the second load still reads voff
 }
+// four rows 32 apart (the four column tiles' rows of one lane: 512 bytes apart in a chunk)
+__device__ __forceinline__ void gload16x4_s(v4u &d0, v4u &d1, v4u &d2, v4u &d3, uint32_t voff, const void *sbase)
+{
+    const void *t;
+    asm volatile("s_mov_b64 %4, %6\n\tglobal_load_dwordx4 %0, %5, %4\n\tglobal_load_dwordx4 %1, %5, %4 offset:512\n\t"
+                 "global_load_dwordx4 %2, %5, %4 offset:1024\n\tglobal_load_dwordx4 %3, %5, %4 offset:1536"
+                 : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&s"(t) : "v"(voff), "s"(sbase));
+}
 __device__ __forceinline__ void gload8_s(v2u &dst, uint32_t voff, const void *sbase)
 {
     const void *t;
@@ -237,9 +245,9 @@ constexpr uint32_t kQueueCap = 128;   // fp32 tier: lane-steps a wave can park f
 #endif
 // dynamic LDS of the kernel: the two j-tile image buffers, the fp64 operand tables, tickets, and for the FP4 triangle
 // kernel the fp32 tables and the four queues
-constexpr size_t mfma_lds_bytes(uint32_t stat_rows, bool f32_tier, bool band_f32 = false)
+constexpr size_t mfma_lds_bytes(uint32_t stat_rows, bool f32_tier, bool band_f32 = false, bool no_image = false)
 {
-    return 2u * kBBuf + (kSlab + kMfmaWaves * stat_rows) * kStat * sizeof(double) + 32u +
+    return (no_image ? 0u : 2u * kBBuf) + (kSlab + kMfmaWaves * stat_rows) * kStat * sizeof(double) + 32u +
            (f32_tier ? (kSlab + kMfmaWaves * kRows64) * 16u + kMfmaWaves * kQueueCap * 36u + kMfmaWaves * 64u * 4u : 0u) +
            (band_f32 ? (kSlab + kMfmaWaves * kRows64) * 16u + kMfmaWaves * kAreaQueue * 8u : 0u);   // the band's float32 screening
                                                                      // tables (same place as the tier's) and candidate queues
@@ -332,9 +340,14 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
 #endif
     extern __shared__ uint4 lds[];
     unsigned char *bexp = reinterpret_cast<unsigned char *>(lds);   // [2][128][144]
+    // The FP4 band (ld_area) keeps NO j-tile image in LDS: every wave loads the bits of "its" four j-rows per lane and
+    // expands them itself, exactly as it does for its i-rows -- no LDS traffic, no workgroup barrier in its K loop
+    // (round 6; LDX_CHUNK_SELF below).  The triangle keeps the shared image: its epilogue wave needs the
+    // issue slots the extra expansion takes.
+    constexpr bool kSelfB = kArea && kFp4;
     // per-SNP operands of the fast epilogue (ldx_common.h, FastCol / FastRow): the j-tile's 128 columns, written
     // once per tile, and this wave's 64 rows, written once per pass
-    double *cstat = reinterpret_cast<double *>(bexp + 2u * kBBuf);   // [128][kStat]: FastCol (+ position, is_query for ld_area)
+    double *cstat = reinterpret_cast<double *>(bexp + (kSelfB ? 0u : 2u * kBBuf));   // [128][kStat]: FastCol (+ position, is_query for ld_area)
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t l32 = lane & 31u;
@@ -603,6 +616,15 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 if constexpr (MM == 2) gload16x2_s(dst[0], dst[1], a_voff, block_base(blk));
                 else gload16_s(dst[0], a_voff, block_base(blk));
             };
+            // kSelfB: this lane's four j-rows (32 tt + l32) of its half's chunk of a K-block, two blocks in registers
+            const uint32_t bs_voff = (uint32_t)((((size_t)t * nchunks + half) * kSlab + l32) * 16u);
+            v4u bq[kSelfB ? 2 : 1][4];
+            auto load_b4 = [&](v4u (&dst)[4], uint32_t blk) { gload16x4_s(dst[0], dst[1], dst[2], dst[3], bs_voff, block_base(blk)); };
+            auto touch_bq = [&](int k) { asm volatile("" : "+v"(bq[k][0]), "+v"(bq[k][1]), "+v"(bq[k][2]), "+v"(bq[k][3])); };
+            auto expand_bq = [&](v4i (&bf)[4], const v4u (&rows)[4], int w) {   // the B fragments of K step w: word w of each row
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) bf[tt] = expand32_b4(rows[tt][w]);
+            };
             // quarter q (K step q) of this thread's share of a K-block, expanded into the image at `buf`
             auto bquarter = [&](unsigned char *buf, const bring_t &bits, int q) {
                 if constexpr (kFp4) {
@@ -616,7 +638,15 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 if constexpr (kFp4) return expand32_a4(x);
                 else return EXPAND_A(x);
             };
-            {
+            if constexpr (kSelfB) {
+                load_b4(bq[0], 0u);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) load_a(ar[k], clampc(k));
+                asm volatile("s_waitcnt vmcnt(0)");
+                touch_bq(0);
+                touch_ring(0);
+                touch_ring(1);
+            } else {
                 bring_t w0;
                 load_b(w0, 0u);
                 load_b(br[1], clampc(1));
@@ -689,7 +719,8 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
             if (kArea) { if (LDX_AB_BANDPRIO == 1 ? (blockIdx.x >= gridDim.x / 2u) : (blockIdx.x & 1u)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
 #endif
             v4i af0[MM], bf0[4], af1[MM], bf1[4];
-            read_bf(bf0, bexp, 0);
+            if constexpr (kSelfB) expand_bq(bf0, bq[0], 0);
+            else read_bf(bf0, bexp, 0);
 #pragma unroll
             for (int m = 0; m < MM; ++m) af0[m] = expand_a(ar[0][m].x);
 
@@ -752,6 +783,60 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 __builtin_amdgcn_sched_barrier(0);                                                                 \
                 LDX_CSTAMP(5)                                                                                      \
             }
+            // ---- the FP4 band's K loop: no LDS image, no barrier (kSelfB) ----
+            // Ring slots as above for the A words (block c in CUR, c + 1 in NXT, FAR receives c + 2); the j-rows' bits of block c
+            // sit in bq[BC], bq[BN] receives block c + 1 (the j-tile is 80 KiB that every wave of the tile's passes reads: L2
+            // hits, one block of cover suffices -- and two blocks are what the register file has room for).  Per block and
+            // lane: 4 + MM loads, 32 MFMA, 40 (A) + 96 (B) vector instructions -- 4.25 per MFMA, which hide behind it --, no LDS
+            // instruction at all.  In flight at the top after this block's batch {B(c+1) x 4, A(c+2) x MM}: that batch only
+            // (the batch before was drained by its own step 3); step 3 needs B(c+1): the MM newest may stay.
+            auto pin_frags = [&](v4i (&af)[MM], v4i (&bf)[4]) {
+                if constexpr (MM == 2) asm volatile("" : "+v"(af[0]), "+v"(af[1]), "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]));
+                else asm volatile("" : "+v"(af[0]), "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]));
+            };
+            auto interleave_self = [&]() {   // 8 x {1 MFMA, up to 5 VALU}
+#pragma unroll
+                for (int k = 0; k < 4 * MM; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, LDX_VALU_PER_MFMA, 0);
+                }
+            };
+#define LDX_CHUNK_SELF(CUR, NXT, FAR, BC, BN, cc)                                                                  \
+            {                                                                                                      \
+                const uint32_t c_ = (cc);                                                                          \
+                load_b4(bq[BN], clampc(c_ + 1u));                                                                  \
+                load_a(ar[FAR], clampc(c_ + 2u));                                                                  \
+                /* step 0: MFMAs of (c,0); prepare (c,1) */                                                        \
+                expand_bq(bf1, bq[BC], 1);                                                                         \
+                _Pragma("unroll") for (int m = 0; m < MM; ++m) af1[m] = expand_a(ar[CUR][m].y);               \
+                mma8(af0, bf0);                                                                                    \
+                interleave_self();                                                                                 \
+                __builtin_amdgcn_sched_barrier(0);                                                                 \
+                /* step 1: MFMAs of (c,1); prepare (c,2) */                                                        \
+                expand_bq(bf0, bq[BC], 2);                                                                         \
+                _Pragma("unroll") for (int m = 0; m < MM; ++m) af0[m] = expand_a(ar[CUR][m].z);               \
+                mma8(af1, bf1);                                                                                    \
+                interleave_self();                                                                                 \
+                __builtin_amdgcn_sched_barrier(0);                                                                 \
+                /* step 2: MFMAs of (c,2); prepare (c,3) */                                                        \
+                expand_bq(bf1, bq[BC], 3);                                                                         \
+                _Pragma("unroll") for (int m = 0; m < MM; ++m) af1[m] = expand_a(ar[CUR][m].w);               \
+                mma8(af0, bf0);                                                                                    \
+                interleave_self();                                                                                 \
+                __builtin_amdgcn_sched_barrier(0);                                                                 \
+                /* step 3: MFMAs of (c,3); prepare (c+1,0): the next block's j-rows and A words must have landed */ \
+                asm volatile("s_waitcnt vmcnt(%0)" : : "n"(MM));                                                   \
+                touch_ring(NXT);                                                                                   \
+                touch_bq(BN);                                                                                      \
+                expand_bq(bf0, bq[BN], 0);                                                                         \
+                _Pragma("unroll") for (int m = 0; m < MM; ++m) af0[m] = expand_a(ar[NXT][m].x);               \
+                mma8(af1, bf1);                                                                                    \
+                /* (the fragments of (c+1,0) are used in the NEXT block: pinned here, or hipcc sinks their 34 vector */ \
+                /* instructions behind this step's MFMAs, onto the loop's back edge, where nothing hides them) */     \
+                pin_frags(af0, bf0);                                                                               \
+                interleave_self();                                                                                 \
+                __builtin_amdgcn_sched_barrier(0);                                                                 \
+            }
             // A wave whose unit lies outside the tile's segment (the last pass of a tile: 2 of 4 units every other tile of the
             // triangle, ~1.5 of 20 in the band's five passes per tile at +-1000 rows) has nothing to count: it keeps up its
             // share of the j-tile image -- the same loads and the same image writes on the same side of the per-block
@@ -771,7 +856,18 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 asm volatile("" : "+v"(br[FAR]));                                                                  \
                 bquarter(bexp + (c_ & 1u) * kBBuf, br[FAR], 0);                                                    \
             }
-            if (__builtin_expect(!active, 0)) {   // wave-uniform
+            if constexpr (kSelfB) {   // (a wave with nothing to count has nothing to contribute either: no shared image)
+                if (active) {
+                    for (uint32_t c = 0; c < nch_run; c += 6) {   // A ring of three, B ring of two: the pattern repeats after six
+                        LDX_CHUNK_SELF(0, 1, 2, 0, 1, c)
+                        if (c + 1 < nch_run) LDX_CHUNK_SELF(1, 2, 0, 1, 0, c + 1)
+                        if (c + 2 < nch_run) LDX_CHUNK_SELF(2, 0, 1, 0, 1, c + 2)
+                        if (c + 3 < nch_run) LDX_CHUNK_SELF(0, 1, 2, 1, 0, c + 3)
+                        if (c + 4 < nch_run) LDX_CHUNK_SELF(1, 2, 0, 0, 1, c + 4)
+                        if (c + 5 < nch_run) LDX_CHUNK_SELF(2, 0, 1, 1, 0, c + 5)
+                    }
+                }
+            } else if (__builtin_expect(!active, 0)) {   // wave-uniform
                 for (uint32_t c = 0; c < nch_run; c += 3) {
                     LDX_CHUNK_IDLE(1, 2, c)
                     if (c + 1 < nch_run) LDX_CHUNK_IDLE(2, 0, c + 1)
@@ -803,12 +899,17 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
             }
 #undef LDX_CHUNK
 #undef LDX_CHUNK_IDLE
+#undef LDX_CHUNK_SELF
             // drain the surplus loads of the last two chunks: their ring registers are about to be reused
             asm volatile("s_waitcnt vmcnt(0)");
             touch_ring(0);
             touch_ring(1);
             touch_ring(2);
             asm volatile("" : "+v"(br[0]), "+v"(br[1]), "+v"(br[2]));
+            if constexpr (kSelfB) {
+                touch_bq(0);
+                touch_bq(1);
+            }
 
 #ifdef LDX_CHUNK_STAMPS
             asm volatile("s_waitcnt lgkmcnt(0)");
@@ -1806,16 +1907,16 @@ int area_mfma(const void *alt, const double *fa, const double *fr, const double 
     area_band_plan_kernel<<<1, 1024, 0, s>>>(positions, n_snps, T, flank, queries, n_query, g_begin, g_end, pass_base,
                                              (unsigned long long *)n_hits, order, first_base, sched);
     LDX_HIP(hipGetLastError());
-    const size_t lds = mfma_lds_bytes(kRows64, false, true);
+    const size_t lds = mfma_lds_bytes(kRows64, false, true, fp4);   // (the FP4 band keeps no j-tile image in LDS)
     {   // above 64 KiB the dynamic LDS size needs the opt-in attribute: once per device
         static std::atomic<uint64_t> opted{0};
         int dev = 0;
         LDX_HIP(hipGetDevice(&dev));
         if (dev < 0 || dev >= 64 || !((opted.load(std::memory_order_relaxed) >> dev) & 1u)) {
             LDX_HIP(hipFuncSetAttribute((const void *)triangle_mfma_kernel<false, false, true, true>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)mfma_lds_bytes(kRows64, false, true, true)));
             LDX_HIP(hipFuncSetAttribute((const void *)triangle_mfma_kernel<false, false, true, false>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)mfma_lds_bytes(kRows64, false, true, false)));
             if (dev >= 0 && dev < 64) opted.fetch_or(1ull << dev, std::memory_order_relaxed);
         }
     }

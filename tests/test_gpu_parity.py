@@ -742,7 +742,7 @@ def test_panels_with_monomorphic_and_missing_code_snps_at_bench_sizes(gpu, n, h)
         del a, b
     codes = codes_d.cpu().numpy()
     flat = (codes == codes[:, :1]).all(axis=1)
-    assert 0.25 * n < flat.sum() < 0.35 * n and 0.1 * n < (codes == 2).any(axis=1).sum() < 0.25 * n
+    assert 0.25 * n < flat.sum() < 0.35 * n and 0.05 * n < (codes == 2).any(axis=1).sum() < 0.25 * n   # (at 1008 haplotypes a flagged row has a code 2 with probability 0.63)
     o = c_oracle.Panel(codes)
     k16 = got.k16.cpu().numpy().view(np.uint16)
     step = 500
@@ -1190,6 +1190,7 @@ def test_triangle_without_a_workspace_deals_passes_round_robin(gpu):
         for path in (3, 2, 0):
             outs = [torch.full_like(ref.k16, -1) for _ in range(2)]
             streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+            torch.cuda.synchronize()                         # the fills run on torch's current stream, the launches on two others
             for o, st in zip(outs, streams):
                 rc = lib.ldx_triangle_ex_dev(p.alt.data_ptr(), p.fa.data_ptr(), p.fr.data_ptr(), p.q.data_ptr(), p.n_snps, p.n_hap,
                                              0, p.n_units, path, _lib.FORMATS["k16"], o.data_ptr(), None, None, None, 0,

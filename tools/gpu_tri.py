@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
-"""Time ld_triangle on a synthetic panel: python tools/gpu_tri.py <snps> <haps> <path> [reps] [ld32|k16]"""
+"""Time ld_triangle on a synthetic panel: python tools/gpu_tri.py <snps> <haps> <path> [reps] [ld32|k16]
+(environment: SYNTH_MONO / SYNTH_MISS / SYNTH_MISS_ROWS = the generator's shares of monomorphic SNPs, of code-2 alleles and of
+the rows that carry them: ld_tools_amd/synth.py)"""
 import json
+import os
 import sys
 from pathlib import Path
 
@@ -13,7 +16,9 @@ n, h, path = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 5
 fmt = sys.argv[5] if len(sys.argv) > 5 else "ld32"
 ops.set_triangle_path(path)
-p = PackedPanel.from_codes(synth.synth_codes_device(n, h))
+p = PackedPanel.from_codes(synth.synth_codes_device(n, h, mono=float(os.environ.get("SYNTH_MONO", 0)),
+                                                    miss=float(os.environ.get("SYNTH_MISS", 0)),
+                                                    miss_rows=float(os.environ.get("SYNTH_MISS_ROWS", 1))))
 res = ld_triangle(p, fmt=fmt)
 torch.cuda.synchronize()
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
