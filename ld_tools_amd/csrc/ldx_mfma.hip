@@ -64,14 +64,6 @@ __device__ __forceinline__ void gload16x2_s(v4u &dst0, v4u &dst1, uint32_t voff,
     asm volatile("s_mov_b64 %2, %4\n\tglobal_load_dwordx4 %0, %3, %2\n\tglobal_load_dwordx4 %1, %3, %2 offset:512"
                  : "=&v"(dst0), "=&v"(dst1), "=&s"(t) : "v"(voff), "s"(sbase));   // early-clobber: the second load still reads voff
 }
-// four rows 32 apart (the four column tiles' rows of one lane: 512 bytes apart in a chunk)
-__device__ __forceinline__ void gload16x4_s(v4u &d0, v4u &d1, v4u &d2, v4u &d3, uint32_t voff, const void *sbase)
-{
-    const void *t;
-    asm volatile("s_mov_b64 %4, %6\n\tglobal_load_dwordx4 %0, %5, %4\n\tglobal_load_dwordx4 %1, %5, %4 offset:512\n\t"
-                 "global_load_dwordx4 %2, %5, %4 offset:1024\n\tglobal_load_dwordx4 %3, %5, %4 offset:1536"
-                 : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&s"(t) : "v"(voff), "s"(sbase));
-}
 __device__ __forceinline__ void gload8_s(v2u &dst, uint32_t voff, const void *sbase)
 {
     const void *t;
@@ -236,6 +228,9 @@ struct AreaArgs {
     int measure;
     F32Const f32;                  // the fp32 epilogue tier's constants (triangle launches use only this member and the next)
 };
+// an entry of the band's ticket order: kAreaDecoded | tile << 12 | pass inside the tile (both < 4096 whenever the order exists:
+// area_order_entries); plain pass indices (no order: panels beyond ~512 000 SNPs) are < 2^30
+constexpr uint32_t kAreaDecoded = 1u << 30;
 constexpr uint32_t kHitBatch = 256;   // hit slots a wave reserves per atomic (as in ldx_area.hip)
 constexpr uint32_t kAreaQueue = 256;  // band: candidate pairs a wave collects before it evaluates them, one per lane
 #ifdef LDX_MM1   // tuning build with three workgroups per CU: 53 KB of LDS each
@@ -245,9 +240,9 @@ constexpr uint32_t kQueueCap = 128;   // fp32 tier: lane-steps a wave can park f
 #endif
 // dynamic LDS of the kernel: the two j-tile image buffers, the fp64 operand tables, tickets, and for the FP4 triangle
 // kernel the fp32 tables and the four queues
-constexpr size_t mfma_lds_bytes(uint32_t stat_rows, bool f32_tier, bool band_f32 = false, bool no_image = false)
+constexpr size_t mfma_lds_bytes(uint32_t stat_rows, bool f32_tier, bool band_f32 = false)
 {
-    return (no_image ? 0u : 2u * kBBuf) + (kSlab + kMfmaWaves * stat_rows) * kStat * sizeof(double) + 32u +
+    return 2u * kBBuf + (kSlab + kMfmaWaves * stat_rows) * kStat * sizeof(double) + 32u +
            (f32_tier ? (kSlab + kMfmaWaves * kRows64) * 16u + kMfmaWaves * kQueueCap * 36u + kMfmaWaves * 64u * 4u : 0u) +
            (band_f32 ? (kSlab + kMfmaWaves * kRows64) * 16u + kMfmaWaves * kAreaQueue * 8u : 0u);   // the band's float32 screening
                                                                      // tables (same place as the tier's) and candidate queues
@@ -340,14 +335,9 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
 #endif
     extern __shared__ uint4 lds[];
     unsigned char *bexp = reinterpret_cast<unsigned char *>(lds);   // [2][128][144]
-    // The FP4 band (ld_area) keeps NO j-tile image in LDS: every wave loads the bits of "its" four j-rows per lane and
-    // expands them itself, exactly as it does for its i-rows -- no LDS traffic, no workgroup barrier in its K loop
-    // (round 6; LDX_CHUNK_SELF below).  The triangle keeps the shared image: its epilogue wave needs the
-    // issue slots the extra expansion takes.
-    constexpr bool kSelfB = kArea && kFp4;
     // per-SNP operands of the fast epilogue (ldx_common.h, FastCol / FastRow): the j-tile's 128 columns, written
     // once per tile, and this wave's 64 rows, written once per pass
-    double *cstat = reinterpret_cast<double *>(bexp + (kSelfB ? 0u : 2u * kBBuf));   // [128][kStat]: FastCol (+ position, is_query for ld_area)
+    double *cstat = reinterpret_cast<double *>(bexp + 2u * kBBuf);   // [128][kStat]: FastCol (+ position, is_query for ld_area)
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t l32 = lane & 31u;
@@ -418,9 +408,9 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 const uint32_t lo = aa.pass_base[(uint32_t)((uint64_t)n_slabs * x / 8u)], hi = aa.pass_base[(uint32_t)((uint64_t)n_slabs * (x + 1u) / 8u)];
                 if (lo == hi) continue;
                 const uint32_t got = atomicAdd(&sched[2u + 32u * x], 1u);
-                if (got < hi - lo) return aa.order ? aa.order[lo + got] : lo + got;
+                if (got < hi - lo) return aa.order ? aa.order[lo + got] : lo + got;   // (a decoded entry, kAreaDecoded, or a plain pass)
             }
-            return n_tickets;   // every range is exhausted
+            return 0xFFFFFFFFu;   // every range is exhausted
         } else {
             // the first gridDim.x tickets are the workgroups' own indices (no atomic round trip before a workgroup's first
             // pass: ~1.5 us per launch); the counter hands out the rest (the grid never exceeds the tickets: launch_mfma).
@@ -446,7 +436,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
         block_sync();   // the ticket is in LDS; every wave is past its previous epilogue (both B buffers free)
         const uint32_t ticket = tickets[parity];
         parity ^= 1u;
-        if (ticket >= n_tickets) {   // block-uniform; the last workgroup out re-arms the counters
+        if (kArea ? ticket == 0xFFFFFFFFu : ticket >= n_tickets) {   // block-uniform; the last workgroup out re-arms the counters
             if (tid == 0 && sched && atomicAdd(&sched[1], 1u) == gridDim.x - 1u) {
                 // (agent-scope atomic stores, never plain ones: store_agent, ldx_common.h.  They go through to the memory side
                 // and are complete when acknowledged, so the order between them needs a wait for the acknowledgement, not a
@@ -460,7 +450,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
             }
             break;
         }
-        const bool short_pass = ticket >= n_norm;                              // block-uniform
+        const bool short_pass = !kArea && ticket >= n_norm;                    // block-uniform
         const uint32_t hsel = short_pass ? (ticket - n_norm) & 1u : 0u;        // which 32-row half
         // The triangle's tickets walk the j-tiles from the LAST to the first (inside a tile forwards): the last tiles are the
         // small ones -- one or two passes each, all on the diagonal, i.e. through the slow general epilogue -- and a launch
@@ -478,6 +468,10 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
             return lo;
         };
         uint32_t t;
+        if (kArea && (ticket & kAreaDecoded)) {   // the plan kernel's ticket order carries the tile and the pass inside it: two
+            t = (ticket >> 12) & 0xFFFu;           // independent loads instead of a binary search through pass_base (~10
+            p = pbase(t) + (ticket & 0xFFFu);      // dependent scalar loads, ~3k cycles at the top of every pass: round 6)
+        } else
 #ifndef LDX_AB_FORWARD_TILES
         if constexpr (!kArea) {
             const uint32_t mirrored = p_end - 1u - seq;   // the pass at the same distance from the end
@@ -616,15 +610,6 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 if constexpr (MM == 2) gload16x2_s(dst[0], dst[1], a_voff, block_base(blk));
                 else gload16_s(dst[0], a_voff, block_base(blk));
             };
-            // kSelfB: this lane's four j-rows (32 tt + l32) of its half's chunk of a K-block, two blocks in registers
-            const uint32_t bs_voff = (uint32_t)((((size_t)t * nchunks + half) * kSlab + l32) * 16u);
-            v4u bq[kSelfB ? 2 : 1][4];
-            auto load_b4 = [&](v4u (&dst)[4], uint32_t blk) { gload16x4_s(dst[0], dst[1], dst[2], dst[3], bs_voff, block_base(blk)); };
-            auto touch_bq = [&](int k) { asm volatile("" : "+v"(bq[k][0]), "+v"(bq[k][1]), "+v"(bq[k][2]), "+v"(bq[k][3])); };
-            auto expand_bq = [&](v4i (&bf)[4], const v4u (&rows)[4], int w) {   // the B fragments of K step w: word w of each row
-#pragma unroll
-                for (int tt = 0; tt < 4; ++tt) bf[tt] = expand32_b4(rows[tt][w]);
-            };
             // quarter q (K step q) of this thread's share of a K-block, expanded into the image at `buf`
             auto bquarter = [&](unsigned char *buf, const bring_t &bits, int q) {
                 if constexpr (kFp4) {
@@ -638,15 +623,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 if constexpr (kFp4) return expand32_a4(x);
                 else return EXPAND_A(x);
             };
-            if constexpr (kSelfB) {
-                load_b4(bq[0], 0u);
-#pragma unroll
-                for (int k = 0; k < 2; ++k) load_a(ar[k], clampc(k));
-                asm volatile("s_waitcnt vmcnt(0)");
-                touch_bq(0);
-                touch_ring(0);
-                touch_ring(1);
-            } else {
+            {
                 bring_t w0;
                 load_b(w0, 0u);
                 load_b(br[1], clampc(1));
@@ -719,8 +696,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
             if (kArea) { if (LDX_AB_BANDPRIO == 1 ? (blockIdx.x >= gridDim.x / 2u) : (blockIdx.x & 1u)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
 #endif
             v4i af0[MM], bf0[4], af1[MM], bf1[4];
-            if constexpr (kSelfB) expand_bq(bf0, bq[0], 0);
-            else read_bf(bf0, bexp, 0);
+            read_bf(bf0, bexp, 0);
 #pragma unroll
             for (int m = 0; m < MM; ++m) af0[m] = expand_a(ar[0][m].x);
 
@@ -783,60 +759,6 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 __builtin_amdgcn_sched_barrier(0);                                                                 \
                 LDX_CSTAMP(5)                                                                                      \
             }
-            // ---- the FP4 band's K loop: no LDS image, no barrier (kSelfB) ----
-            // Ring slots as above for the A words (block c in CUR, c + 1 in NXT, FAR receives c + 2); the j-rows' bits of block c
-            // sit in bq[BC], bq[BN] receives block c + 1 (the j-tile is 80 KiB that every wave of the tile's passes reads: L2
-            // hits, one block of cover suffices -- and two blocks are what the register file has room for).  Per block and
-            // lane: 4 + MM loads, 32 MFMA, 40 (A) + 96 (B) vector instructions -- 4.25 per MFMA, which hide behind it --, no LDS
-            // instruction at all.  In flight at the top after this block's batch {B(c+1) x 4, A(c+2) x MM}: that batch only
-            // (the batch before was drained by its own step 3); step 3 needs B(c+1): the MM newest may stay.
-            auto pin_frags = [&](v4i (&af)[MM], v4i (&bf)[4]) {
-                if constexpr (MM == 2) asm volatile("" : "+v"(af[0]), "+v"(af[1]), "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]));
-                else asm volatile("" : "+v"(af[0]), "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]));
-            };
-            auto interleave_self = [&]() {   // 8 x {1 MFMA, up to 5 VALU}
-#pragma unroll
-                for (int k = 0; k < 4 * MM; ++k) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, LDX_VALU_PER_MFMA, 0);
-                }
-            };
-#define LDX_CHUNK_SELF(CUR, NXT, FAR, BC, BN, cc)                                                                  \
-            {                                                                                                      \
-                const uint32_t c_ = (cc);                                                                          \
-                load_b4(bq[BN], clampc(c_ + 1u));                                                                  \
-                load_a(ar[FAR], clampc(c_ + 2u));                                                                  \
-                /* step 0: MFMAs of (c,0); prepare (c,1) */                                                        \
-                expand_bq(bf1, bq[BC], 1);                                                                         \
-                _Pragma("unroll") for (int m = 0; m < MM; ++m) af1[m] = expand_a(ar[CUR][m].y);               \
-                mma8(af0, bf0);                                                                                    \
-                interleave_self();                                                                                 \
-                __builtin_amdgcn_sched_barrier(0);                                                                 \
-                /* step 1: MFMAs of (c,1); prepare (c,2) */                                                        \
-                expand_bq(bf0, bq[BC], 2);                                                                         \
-                _Pragma("unroll") for (int m = 0; m < MM; ++m) af0[m] = expand_a(ar[CUR][m].z);               \
-                mma8(af1, bf1);                                                                                    \
-                interleave_self();                                                                                 \
-                __builtin_amdgcn_sched_barrier(0);                                                                 \
-                /* step 2: MFMAs of (c,2); prepare (c,3) */                                                        \
-                expand_bq(bf1, bq[BC], 3);                                                                         \
-                _Pragma("unroll") for (int m = 0; m < MM; ++m) af1[m] = expand_a(ar[CUR][m].w);               \
-                mma8(af0, bf0);                                                                                    \
-                interleave_self();                                                                                 \
-                __builtin_amdgcn_sched_barrier(0);                                                                 \
-                /* step 3: MFMAs of (c,3); prepare (c+1,0): the next block's j-rows and A words must have landed */ \
-                asm volatile("s_waitcnt vmcnt(%0)" : : "n"(MM));                                                   \
-                touch_ring(NXT);                                                                                   \
-                touch_bq(BN);                                                                                      \
-                expand_bq(bf0, bq[BN], 0);                                                                         \
-                _Pragma("unroll") for (int m = 0; m < MM; ++m) af0[m] = expand_a(ar[NXT][m].x);               \
-                mma8(af1, bf1);                                                                                    \
-                /* (the fragments of (c+1,0) are used in the NEXT block: pinned here, or hipcc sinks their 34 vector */ \
-                /* instructions behind this step's MFMAs, onto the loop's back edge, where nothing hides them) */     \
-                pin_frags(af0, bf0);                                                                               \
-                interleave_self();                                                                                 \
-                __builtin_amdgcn_sched_barrier(0);                                                                 \
-            }
             // A wave whose unit lies outside the tile's segment (the last pass of a tile: 2 of 4 units every other tile of the
             // triangle, ~1.5 of 20 in the band's five passes per tile at +-1000 rows) has nothing to count: it keeps up its
             // share of the j-tile image -- the same loads and the same image writes on the same side of the per-block
@@ -856,18 +778,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 asm volatile("" : "+v"(br[FAR]));                                                                  \
                 bquarter(bexp + (c_ & 1u) * kBBuf, br[FAR], 0);                                                    \
             }
-            if constexpr (kSelfB) {   // (a wave with nothing to count has nothing to contribute either: no shared image)
-                if (active) {
-                    for (uint32_t c = 0; c < nch_run; c += 6) {   // A ring of three, B ring of two: the pattern repeats after six
-                        LDX_CHUNK_SELF(0, 1, 2, 0, 1, c)
-                        if (c + 1 < nch_run) LDX_CHUNK_SELF(1, 2, 0, 1, 0, c + 1)
-                        if (c + 2 < nch_run) LDX_CHUNK_SELF(2, 0, 1, 0, 1, c + 2)
-                        if (c + 3 < nch_run) LDX_CHUNK_SELF(0, 1, 2, 1, 0, c + 3)
-                        if (c + 4 < nch_run) LDX_CHUNK_SELF(1, 2, 0, 0, 1, c + 4)
-                        if (c + 5 < nch_run) LDX_CHUNK_SELF(2, 0, 1, 1, 0, c + 5)
-                    }
-                }
-            } else if (__builtin_expect(!active, 0)) {   // wave-uniform
+            if (__builtin_expect(!active, 0)) {   // wave-uniform
                 for (uint32_t c = 0; c < nch_run; c += 3) {
                     LDX_CHUNK_IDLE(1, 2, c)
                     if (c + 1 < nch_run) LDX_CHUNK_IDLE(2, 0, c + 1)
@@ -899,17 +810,12 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
             }
 #undef LDX_CHUNK
 #undef LDX_CHUNK_IDLE
-#undef LDX_CHUNK_SELF
             // drain the surplus loads of the last two chunks: their ring registers are about to be reused
             asm volatile("s_waitcnt vmcnt(0)");
             touch_ring(0);
             touch_ring(1);
             touch_ring(2);
             asm volatile("" : "+v"(br[0]), "+v"(br[1]), "+v"(br[2]));
-            if constexpr (kSelfB) {
-                touch_bq(0);
-                touch_bq(1);
-            }
 
 #ifdef LDX_CHUNK_STAMPS
             asm volatile("s_waitcnt lgkmcnt(0)");
@@ -1831,9 +1737,9 @@ __global__ void __launch_bounds__(1024) area_band_plan_kernel(const int64_t *__r
         const uint32_t r0 = pass_base[a];
 #ifdef LDX_AB_FIRST_FIRST   // round 4's order: all first passes of the range, then all the others (each range swept twice)
         const uint32_t nfirst = first_base[b] - first_base[a], kf = first_base[t] - first_base[a];
-        order[r0 + kf] = pb;
+        order[r0 + kf] = kAreaDecoded | (t << 12);
         const uint32_t lt = (pb - r0) - kf;   // passes other than first ones before this tile, inside the range
-        for (uint32_t i = 1; i < cnt; ++i) order[r0 + nfirst + lt + (i - 1u)] = pb + i;
+        for (uint32_t i = 1; i < cnt; ++i) order[r0 + nfirst + lt + (i - 1u)] = kAreaDecoded | (t << 12) | i;
 #else
         // Round 5: ONE sweep per range.  A tile's first pass is still handed out early -- kLead tiles ahead of the tile whose
         // other passes are being handed out, i.e. while the rows of ITS diagonal are inside the band that is streaming
@@ -1845,9 +1751,10 @@ __global__ void __launch_bounds__(1024) area_band_plan_kernel(const int64_t *__r
         constexpr uint32_t kLead = 8;
         auto F = [&](uint32_t tt) { return first_base[tt] - first_base[a]; };
         auto L = [&](uint32_t tt) { return (pass_base[tt] - r0) - F(tt); };
-        order[r0 + F(t) + L(t >= a + kLead ? t - kLead : a)] = pb;
+        // (entries carry the tile and the pass inside it, kAreaDecoded: the band kernel need not search pass_base for them)
+        order[r0 + F(t) + L(t >= a + kLead ? t - kLead : a)] = kAreaDecoded | (t << 12);
         const uint32_t ahead = t + kLead + 1u < b ? t + kLead + 1u : b;
-        for (uint32_t i = 1; i < cnt; ++i) order[r0 + F(ahead) + L(t) + (i - 1u)] = pb + i;
+        for (uint32_t i = 1; i < cnt; ++i) order[r0 + F(ahead) + L(t) + (i - 1u)] = kAreaDecoded | (t << 12) | i;
 #endif
     }
 }
@@ -1860,7 +1767,7 @@ static size_t area_order_entries(uint32_t n_snps)
 {
     const uint32_t T = n_slabs(n_snps);
     const size_t worst = mfma_pass_base(T, T);
-    return worst <= kOrderCap ? worst : 0u;
+    return (worst <= kOrderCap && T < 4096u) ? worst : 0u;   // (T < 4096: an order entry packs tile and pass-in-tile in 12 bits each)
 }
 
 size_t area_mfma_workspace_bytes(uint32_t n_snps)
@@ -1907,16 +1814,16 @@ int area_mfma(const void *alt, const double *fa, const double *fr, const double 
     area_band_plan_kernel<<<1, 1024, 0, s>>>(positions, n_snps, T, flank, queries, n_query, g_begin, g_end, pass_base,
                                              (unsigned long long *)n_hits, order, first_base, sched);
     LDX_HIP(hipGetLastError());
-    const size_t lds = mfma_lds_bytes(kRows64, false, true, fp4);   // (the FP4 band keeps no j-tile image in LDS)
+    const size_t lds = mfma_lds_bytes(kRows64, false, true);
     {   // above 64 KiB the dynamic LDS size needs the opt-in attribute: once per device
         static std::atomic<uint64_t> opted{0};
         int dev = 0;
         LDX_HIP(hipGetDevice(&dev));
         if (dev < 0 || dev >= 64 || !((opted.load(std::memory_order_relaxed) >> dev) & 1u)) {
             LDX_HIP(hipFuncSetAttribute((const void *)triangle_mfma_kernel<false, false, true, true>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)mfma_lds_bytes(kRows64, false, true, true)));
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             LDX_HIP(hipFuncSetAttribute((const void *)triangle_mfma_kernel<false, false, true, false>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)mfma_lds_bytes(kRows64, false, true, false)));
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             if (dev >= 0 && dev < 64) opted.fetch_or(1ull << dev, std::memory_order_relaxed);
         }
     }
