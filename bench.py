@@ -292,6 +292,16 @@ def other_workloads(torch, dev, fmt, bench_codes, scale="full", corrupt=False):
         o.cells.fill_(-1)
         reps = 9
         ms, ms_min, ms_all = timed_launches(lambda: ld_triangle(p, out=o, fmt=fmt), reps)
+        # the same panel through the one-measure path (2 B/pair: what ld_triangle's table writer asks for, one measure per
+        # run; never the headline: the metric is r2 + D'); every cell against the r2 half of the two-value result
+        one = ld_triangle(p, fmt="k16r") if fmt == "k16" else None
+        if one is not None:
+            for _ in range(3 if small else 10):
+                ld_triangle(p, out=one, fmt="k16r")
+            torch.cuda.synchronize()
+            one.cells.fill_(-1)
+            ms1, ms1_min, ms1_all = timed_launches(lambda: ld_triangle(p, out=one, fmt="k16r"), reps)
+            same_one = bool(torch.equal(one.k16one, o.k16[:, 0].contiguous()))
         if corrupt:                                              # test hook (--debug-corrupt-other)
             o.cells.view(torch.int32).view(-1)[4321] ^= 1
         chk = ld_triangle(p, fmt=fmt, path="popcount")          # the independent kernel (AND + popcount, fp64 epilogue)
@@ -307,6 +317,16 @@ def other_workloads(torch, dev, fmt, bench_codes, scale="full", corrupt=False):
             "roofline_hbm": {"bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": alg},
             "frac_of_fp4_peak": 2.0 * h * pairs / (ms * 1e-3) / 1e12 / MFMA_FP4_PEAK_TOPS}
+        if one is not None:
+            alg1 = 2.0 * pairs + lib.ldx_plane_bytes(n, h)
+            res[key4 + ", r2 only (2 B/pair)"] = {
+                "ms": ms1, "ms_min": ms1_min, "ms_runs": ms1_all, "pairs_per_s": pairs / (ms1 * 1e-3), "fmt": "k16r",
+                "what": "LDX_OUT_K16_RSQ: one measure per pair, the other value's arithmetic skipped (the table writer's path)",
+                "verified_against": "the r2 half of every cell of the two-value result above", "results_equal": same_one,
+                "launches": reps,
+                "roofline_hbm": {"bound": "hbm", "achieved": alg1 / (ms1 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": alg1 / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": alg1}}
+            del one
         del o, p
         torch.cuda.empty_cache()
     except Exception as exc:   # noqa: BLE001  (a reported extra, never a reason to lose the bench line)

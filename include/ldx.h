@@ -39,7 +39,8 @@
 extern "C" {
 #endif
 
-#define LDX_VERSION 102            /* 0.1.2: ldx_triangle_ex_dev takes the pass scheduler's workspace (the library keeps no per-stream state) */
+#define LDX_VERSION 102            /* 0.1.2: ldx_triangle_ex_dev takes the pass scheduler's workspace (the library keeps no per-stream
+                                      state); one-measure cell formats LDX_OUT_K16_RSQ / LDX_OUT_K16_DPRIME */
 #define LDX_SLAB_ROWS 128u         /* SNP rows per slab == SNP columns per j-tile */
 #define LDX_GROUP_ROWS 8u          /* SNP rows a wavefront pairs against one j-tile per unit */
 #define LDX_CHUNK_HAPS 128u        /* haplotypes per 16-byte chunk */
@@ -59,7 +60,7 @@ extern "C" {
  * MFMA operand roles swapped) was slower; this order needs no change to the arithmetic. */
 #define LDX_CELL_OFFSET4(r8, c) ((r8) * LDX_SLAB_ROWS + (((c) & 31u) << 2) + ((c) >> 5))
 #define LDX_CELL_OFFSET8(r8, c) ((r8) * LDX_SLAB_ROWS + (((c) >> 6) << 6) + (((c) & 31u) << 1) + (((c) >> 5) & 1u))
-#define LDX_CELL_OFFSET(out_format, r8, c) ((out_format) == LDX_OUT_K16 ? LDX_CELL_OFFSET4(r8, c) : LDX_CELL_OFFSET8(r8, c))
+#define LDX_CELL_OFFSET(out_format, r8, c) ((out_format) == LDX_OUT_LD32 ? LDX_CELL_OFFSET8(r8, c) : LDX_CELL_OFFSET4(r8, c))
 #define LDX_MAX_HAPS 10240u        /* one j-tile (128 rows, all chunks) must fit 160 KiB of LDS */
 
 /* error codes */
@@ -96,6 +97,13 @@ typedef struct { double r_square; double d_prime; } ldx_ld64;   /* unrounded, fo
 #define LDX_K16_BIG 0x7FFFu
 #define LDX_OUT_LD32 0
 #define LDX_OUT_K16 1
+/* ONE measure per pair, 2 bytes (round 6): the r_square half or the d_prime half of ldx_k16 alone -- what a caller that writes
+ * one measure needs (ld_triangle.py:223-230,344-360 fill and print ld_two_dim for the ONE measure -l names).  Same element
+ * order as ldx_k16 (LDX_CELL_OFFSET4), same k / int-0 bit / escape.  The kernel skips the other value's arithmetic, margin
+ * and bytes.  No side outputs (out_raw, out_n11) with these formats. */
+typedef struct { uint16_t value; } ldx_k16one;
+#define LDX_OUT_K16_RSQ 2
+#define LDX_OUT_K16_DPRIME 3
 
 /* one ld_area hit (ld_area.py:261-271): query/opposing SNP row indices and rounded values */
 typedef struct {
@@ -192,8 +200,9 @@ int ldx_triangle_dev(const void *alt, const double *fa, const double *fr, const 
 #define LDX_PATH_FP4 3
 int ldx_set_triangle_path(int path);
 int ldx_get_triangle_path(void);
-/* ldx_triangle_dev with the kernel path and the cell format per call.  out: ldx_ld32 or ldx_k16 cells
- * (out_format = LDX_OUT_LD32 / LDX_OUT_K16), indexed as in ldx_triangle_dev.  out_raw needs LDX_OUT_LD32.
+/* ldx_triangle_dev with the kernel path and the cell format per call.  out: ldx_ld32, ldx_k16 or ldx_k16one cells
+ * (out_format = LDX_OUT_LD32 / LDX_OUT_K16 / LDX_OUT_K16_RSQ / LDX_OUT_K16_DPRIME), indexed as in ldx_triangle_dev.  out_raw
+ * needs LDX_OUT_LD32; the one-measure formats take neither side output and run on the FP4 or the popcount kernel.
  * workspace (ABI 102): ldx_triangle_workspace_bytes() bytes of device memory, 256-byte aligned, that hold the matrix
  * kernel's pass scheduler (two ticket counters).  Contract:
  *   - ZERO it once before the first launch that uses it (hipMemsetAsync, torch.zeros, or ldx_triangle_workspace_init_dev);
@@ -219,8 +228,9 @@ int ldx_triangle_ex_dev(const void *alt, const double *fa, const double *fr, con
 int ldx_triangle_dense_dev(const ldx_ld32 *strips, uint32_t n_snps, int measure, int has_thres,
                            double thres, uint32_t row_begin, uint32_t row_end, float *dense,
                            size_t ld, void *stream);
-/* The same for either cell format (strips_format = LDX_OUT_LD32 / LDX_OUT_K16).  Escape cells (values the format
- * cannot hold) come out as the NaN LDX_LD32_BIG_BITS whatever the threshold: resolve them with ldx_ld_pairs_dev. */
+/* The same for any cell format (strips_format = LDX_OUT_*; a one-measure format holds ONE measure: `measure` must be it).
+ * Escape cells (values the format cannot hold) come out as the NaN LDX_LD32_BIG_BITS whatever the threshold: resolve them
+ * with ldx_ld_pairs_dev. */
 int ldx_triangle_dense_ex_dev(const void *strips, int strips_format, uint32_t n_snps, int measure, int has_thres,
                               double thres, uint32_t row_begin, uint32_t row_end, float *dense,
                               size_t ld, void *stream);

@@ -24,7 +24,7 @@ def cell_offset(r8, c, fmt="k16"):
     """LDX_CELL_OFFSET of include/ldx.h: element of cell (row % 8, column % 128) inside its unit, in the order of the cell
     format: rows one after the other; inside a row the columns {c0, c0 + 32, c0 + 64, c0 + 96} one lane of the matrix kernel
     holds are adjacent (k16: all four; ld32: in two pairs).  Works on ints and numpy arrays."""
-    if fmt == "k16":
+    if fmt in ("k16", "k16r", "k16d"):
         return r8 * SLAB_ROWS + ((c & 31) << 2) + (c >> 5)
     if fmt != "ld32":
         raise ValueError(f"unknown cell format {fmt!r}")
@@ -35,7 +35,9 @@ MAX_HAPS = 10240
 FLAG_DPRIME_INT0 = 1
 FLAG_RSQ_INT0 = 2
 MEASURES = {"r_square": 0, "d_prime": 1}
-FORMATS = {"ld32": 0, "k16": 1}          # LDX_OUT_LD32 / LDX_OUT_K16
+FORMATS = {"ld32": 0, "k16": 1, "k16r": 2, "k16d": 3}   # LDX_OUT_LD32 / LDX_OUT_K16 / LDX_OUT_K16_RSQ / LDX_OUT_K16_DPRIME
+ONE_MEASURE = {"k16r": "r_square", "k16d": "d_prime"}    # the one-measure formats (2-byte cells) and what they hold
+ONE_MEASURE_FMT = {v: k for k, v in ONE_MEASURE.items()}
 LD32_BIG_BITS = 0x7FC00B16               # ldx_ld32 escape (value >= 1024): a quiet NaN
 K16_INT0 = 0x8000
 K16_BIG = 0x7FFF

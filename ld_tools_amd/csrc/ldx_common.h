@@ -155,6 +155,14 @@ constexpr double kBig32 = 1.024e7;
 template <typename Cell>
 __device__ __forceinline__ Cell encode_cell(double kr, double kd, bool r_int0, bool d_int0);
 
+// the one-measure cells of include/ldx.h (ldx_k16one) as two types, so that the kernels know at compile time which value
+// to compute: the r_square half / the d_prime half of ldx_k16
+struct ldx_k16r { uint16_t value; };
+struct ldx_k16d { uint16_t value; };
+template <typename Cell> struct cell_measure { static constexpr int value = -1; };                  // both values
+template <> struct cell_measure<ldx_k16r> { static constexpr int value = LDX_MEASURE_RSQ; };
+template <> struct cell_measure<ldx_k16d> { static constexpr int value = LDX_MEASURE_DPRIME; };
+
 template <>
 __device__ __forceinline__ ldx_ld32 encode_cell<ldx_ld32>(double kr, double kd, bool r_int0, bool d_int0)
 {
@@ -173,11 +181,23 @@ __device__ __forceinline__ ldx_k16 encode_cell<ldx_k16>(double kr, double kd, bo
     return o;
 }
 
+template <>
+__device__ __forceinline__ ldx_k16r encode_cell<ldx_k16r>(double kr, double, bool r_int0, bool)
+{
+    return ldx_k16r{r_int0 ? (uint16_t)LDX_K16_INT0 : (kr < 32767.0 ? (uint16_t)(uint32_t)kr : (uint16_t)LDX_K16_BIG)};
+}
+
+template <>
+__device__ __forceinline__ ldx_k16d encode_cell<ldx_k16d>(double, double kd, bool, bool d_int0)
+{
+    return ldx_k16d{d_int0 ? (uint16_t)LDX_K16_INT0 : (kd < 32767.0 ? (uint16_t)(uint32_t)kd : (uint16_t)LDX_K16_BIG)};
+}
+
 // element of cell (row % 8, column % 128) inside its unit, in the order of the cell format (include/ldx.h)
 template <typename Cell>
 __host__ __device__ __forceinline__ uint32_t cell_offset(uint32_t r8, uint32_t c)
 {
-    if constexpr (sizeof(Cell) == 4) return LDX_CELL_OFFSET4(r8, c);
+    if constexpr (sizeof(Cell) <= 4) return LDX_CELL_OFFSET4(r8, c);
     else return LDX_CELL_OFFSET8(r8, c);
 }
 
@@ -187,6 +207,10 @@ template <>
 __device__ __forceinline__ ldx_ld32 zero_cell<ldx_ld32>() { return ldx_ld32{0.0f, 0.0f}; }
 template <>
 __device__ __forceinline__ ldx_k16 zero_cell<ldx_k16>() { return ldx_k16{0, 0}; }
+template <>
+__device__ __forceinline__ ldx_k16r zero_cell<ldx_k16r>() { return ldx_k16r{0}; }
+template <>
+__device__ __forceinline__ ldx_k16d zero_cell<ldx_k16d>() { return ldx_k16d{0}; }
 
 template <typename Cell>
 __device__ __forceinline__ Cell encode_cell(const LdK &k)
@@ -392,7 +416,13 @@ __device__ __forceinline__ void ld_multi_fast2(const T (&cnt_scaled)[W], const F
               if (!kClean) { ok[t_] = ok[t_] & (mx[t_] < 1e7); deg[t_] = inv[t_] == __builtin_inf(); }
               if (kF32) kr[t_] = kr[t_] * 1e-4)
     LDX_STAGE(ok[t_] = ok[t_] & (__builtin_fabs(ed[t_]) < hd[t_]); if (kF32) kd[t_] = kd[t_] * 1e-4)
-    if constexpr (kF32) {
+    if constexpr (cell_measure<Cell>::value >= 0) {   // one value: its k in 15 bits; the other value's margin still counts (a pair
+        // near a tie of EITHER value takes the caller's slow path: correct, and this tier is not where the time goes)
+        LDX_STAGE(const uint32_t u = (uint32_t)(cell_measure<Cell>::value == LDX_MEASURE_RSQ ? kr[t_] : kd[t_]);
+                  if (kClean) { out[t_].value = (uint16_t)u; slow[t_] = !ok[t_]; }
+                  else { out[t_].value = deg[t_] ? (uint16_t)LDX_K16_INT0 : (uint16_t)u;
+                         slow[t_] = !((ok[t_] & (u < 32767u)) | deg[t_]); })
+    } else if constexpr (kF32) {
         LDX_STAGE(const float vr = (float)kr[t_]; const float vd = (float)kd[t_];   // float32 nearest to k / 10^4 (k < 10^7 here)
                   if (kClean) { out[t_].r_square = vr; out[t_].d_prime = vd; slow[t_] = !ok[t_]; }
                   else { out[t_].r_square = deg[t_] ? -0.0f : vr; out[t_].d_prime = deg[t_] ? -0.0f : vd;
@@ -466,25 +496,27 @@ __host__ __device__ inline F32Const f32_const(double n)
 // epilogue_f32, kDeg) and the table entries only have to keep the margin test quiet: a fake count A (1 for a == 0, n + 1
 // for a == n) makes  Dn = n c - A1 A2  a NEGATIVE NON-ZERO integer against every other entry -- c is 0 for an all-REF
 // SNP and a_X for an all-ALT one, so Dn = -A_X resp. a_X n - (n + 1) A_X = -a_X (ordinary X), -(n + 1), -(2n + 1) -- the
-// sign picks x = ra, y = rr;  ra = eps, rr = 0, s = 0  give  y_r = 0  and a tiny positive  y_d  (eps_r = 2^-10 against an
-// ordinary column: y_d = a_X eps_r fl(1 / a_X); eps_c = 2^-24 against an ordinary row: 10^4 eps_c; both: <= (2n + 2) 2^-34):
-// both round to 0 with a margin near 0, min y_d > 0 holds, nothing parks.  (30 % monomorphic rows at 50 000 x 1008 -- a
+// sign picks x = ra, y = rr;  ra = eps, rr = 0, s = 2^-20  give tiny positive  y_r = (Dn s1 s2)^2 < 0.01  and  y_d  (eps_r =
+// 2^-10 against an ordinary column: y_d = a_X eps_r fl(1 / a_X); eps_c = 2^-24 against an ordinary row: 10^4 eps_c; both:
+// <= (2n + 2) 2^-34): both round to 0 with a margin near 0, min y_d > 0 (and, in the one-measure r^2 variant, |Dn s1 s2| > 0)
+// holds, nothing parks.  s = 2^-20 is also what MARKS such an entry (an ordinary s is >= 20 / n, kSnpOdd's is 0).  (30 % monomorphic rows at 50 000 x 1008 -- a
 // sub-panel of the ALL-panel variants -- sent EVERY unit through the fp64 epilogue before: bench.py, other_workloads.)
+constexpr float kDegS = 0x1p-20f;   // the `s` entry of a degenerate SNP: marks it, and keeps Dn s1 s2 non-zero
 __device__ __forceinline__ F32Row f32_row(double a, double ra, double rr, int cls, double n)
 {
     if (cls == kSnpOdd) return F32Row{0.0f, 0.0f, 0.0f, 0.0f};
-    if (cls == kSnpDegenerate) return F32Row{a == 0.0 ? 1.0f : (float)(n + 1.0), 0x1p-10f, 0.0f, 0.0f};
+    if (cls == kSnpDegenerate) return F32Row{a == 0.0 ? 1.0f : (float)(n + 1.0), 0x1p-10f, 0.0f, kDegS};
     return F32Row{(float)a, (float)(1e4 * ra), (float)(1e4 * rr), (float)(10.0 * __builtin_sqrt(ra * rr))};
 }
 
 __device__ __forceinline__ F32Col f32_col(double a, double ra, double rr, int cls, double n)
 {
     if (cls == kSnpOdd) return F32Col{0.0f, 0.0f, 0.0f, 0.0f};
-    if (cls == kSnpDegenerate) return F32Col{a == 0.0 ? 1.0f : (float)(n + 1.0), 0x1p-24f, 0.0f, 0.0f};
+    if (cls == kSnpDegenerate) return F32Col{a == 0.0 ? 1.0f : (float)(n + 1.0), 0x1p-24f, 0.0f, kDegS};
     return F32Col{(float)a, (float)ra, (float)rr, (float)(10.0 * __builtin_sqrt(ra * rr))};
 }
-// a table entry of a kSnpDegenerate SNP (s == 0 marks "not ordinary", ra / ra_s != 0 tells it from kSnpOdd's zeros)
-__device__ __forceinline__ bool f32_entry_degenerate(float ra, float s) { return s == 0.0f && ra != 0.0f; }
+// a table entry of a kSnpDegenerate SNP
+__device__ __forceinline__ bool f32_entry_degenerate(float, float s) { return s == kDegS; }
 
 // dst = lane's mask bit ? forced : keep, the mask a wave-uniform 64-bit value (SALU-made: s_or_b64 of a row and a column mask).
 // __builtin_amdgcn_inverse_ballot_w64 hands the scalar mask to the compiler AS a lane mask: it emits  s_or_b64 vcc, .. ;
@@ -558,6 +590,47 @@ __device__ __forceinline__ void ld_multi_f32(const float (&cnt)[W], const F32Con
     } else {
         LDX_STAGE(out[t_].r_square = f32_k_to_value(kr[t_]); out[t_].d_prime = f32_k_to_value(kd[t_]))
     }
+}
+// The same tier for ONE measure (the 2-byte cells): the other value's products, rounding and margin are not computed --
+// r^2 alone: 12 instructions per pair (11 at n <= 4096), D' alone: 14 (13) -- against 24.5.  bits[] receive the float32 bit
+// patterns of 2^23 + k: the cell is their low 16 bits (the caller packs two cells per byte permute).  ymin tracks what keeps
+// Dn == 0 and kSnpOdd SNPs (all-zero entries) parking: |Dn s1 s2| for r^2, y_d for D'.
+template <int W, int kMeasure, bool kSmallN = false, bool kSplit = false>
+__device__ __forceinline__ void ld_multi_f32_one(const float (&cnt)[W], const F32Const &k, const F32Row (&r)[W],
+                                                 const F32Col (&c)[W], uint32_t (&bits)[W], float &wmax, float &ymin,
+                                                 const float *al = nullptr)
+{
+    float p[W], e[W], dn[W], t[W], yv[W], x[W], y[W], av[W], kv[W], fv[W];
+    __builtin_amdgcn_sched_barrier(0);
+    LDX_STAGE(p[t_] = r[t_].a * c[t_].a)
+    if constexpr (kSmallN) {
+        LDX_STAGE(dn[t_] = __builtin_fmaf(cnt[t_], k.n, -p[t_]))
+    } else if constexpr (kSplit) {
+        LDX_STAGE(dn[t_] = __builtin_fmaf(cnt[t_], k.n, -p[t_]))
+        LDX_STAGE(dn[t_] = __builtin_fmaf(-r[t_].a, al[t_], dn[t_]))
+    } else {
+        LDX_STAGE(e[t_] = __builtin_fmaf(r[t_].a, c[t_].a, -p[t_]); dn[t_] = __builtin_fmaf(cnt[t_], k.n, -p[t_]))
+        LDX_STAGE(dn[t_] = dn[t_] - e[t_])
+    }
+    if constexpr (kMeasure == LDX_MEASURE_RSQ) {
+        LDX_STAGE(t[t_] = dn[t_] * r[t_].s)
+        LDX_STAGE(t[t_] = t[t_] * c[t_].s)
+        LDX_STAGE(yv[t_] = t[t_] * t[t_])                                              // 1e4 r^2
+        LDX_STAGE(av[t_] = yv[t_] + kMagic; ymin = __builtin_fminf(ymin, __builtin_fabsf(t[t_])))   // 0: Dn == 0, or a kSnpOdd SNP
+        LDX_STAGE(kv[t_] = av[t_] - kMagic)
+        LDX_STAGE(fv[t_] = yv[t_] - kv[t_])
+        LDX_STAGE(fv[t_] = __builtin_fmaf(yv[t_], kEtaR, __builtin_fabsf(fv[t_])))
+    } else {
+        LDX_STAGE(const bool neg = dn[t_] < 0.0f; x[t_] = neg ? c[t_].ra : c[t_].rr; y[t_] = neg ? c[t_].rr : c[t_].ra)
+        LDX_STAGE(x[t_] = r[t_].ra_s * x[t_]; y[t_] = r[t_].rr_s * y[t_])
+        LDX_STAGE(x[t_] = __builtin_fmaxf(x[t_], y[t_]))                               // 1e4 / B
+        LDX_STAGE(yv[t_] = __builtin_fabsf(dn[t_]) * x[t_])                            // 1e4 D'
+        LDX_STAGE(av[t_] = yv[t_] + kMagic; ymin = __builtin_fminf(ymin, yv[t_]))
+        LDX_STAGE(kv[t_] = av[t_] - kMagic)
+        LDX_STAGE(fv[t_] = yv[t_] - kv[t_])
+        LDX_STAGE(fv[t_] = __builtin_fmaf(yv[t_], kEtaD, __builtin_fabsf(fv[t_])))
+    }
+    LDX_STAGE(wmax = __builtin_fmaxf(wmax, fv[t_]); bits[t_] = __float_as_uint(av[t_]))
 }
 #undef LDX_STAGE
 

@@ -261,10 +261,21 @@ constexpr uint32_t kStatRows = kRows64;
 template <typename Cell>
 __device__ __forceinline__ void store_cell(Cell *p, Cell v)
 {
-    if constexpr (sizeof(Cell) == 4)
+    if constexpr (sizeof(Cell) == 2)
+        __builtin_nontemporal_store(__builtin_bit_cast(uint16_t, v), reinterpret_cast<uint16_t *>(p));
+    else if constexpr (sizeof(Cell) == 4)
         __builtin_nontemporal_store(__builtin_bit_cast(uint32_t, v), reinterpret_cast<uint32_t *>(p));
     else
         __builtin_nontemporal_store(__builtin_bit_cast(unsigned long long, v), reinterpret_cast<unsigned long long *>(p));
+}
+
+// A lane's four 2-byte cells of one row (the one-measure formats), already packed two per word: one 8-byte store
+template <typename Cell>
+__device__ __forceinline__ void store_words2_saddr(Cell *sbase, uint32_t voff_bytes, uint32_t w0, uint32_t w1)
+{
+    Cell *t;   // (the base through an s_mov_b64 inside the asm: see gload16_s)
+    const v2u v = {w0, w1};
+    asm volatile("s_mov_b64 %0, %3\n\tglobal_store_dwordx2 %1, %2, %0 nt" : "=&s"(t) : "v"(voff_bytes), "v"(v), "s"(sbase) : "memory");
 }
 
 // The same store with a SCALAR base and a 32-bit per-lane byte offset (`global_store_dword voff, vdata, s[base:base+1]`):
@@ -1008,7 +1019,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 // rows e and e + 4 of a group of 8 belong to the two lane halves; a lane's four columns (l32 + 32 tt) are adjacent
                 // cells of the row (include/ldx.h: 4 l32 .. 4 l32 + 3 for 4-byte cells; the pairs 2 l32, 2 l32 + 1 and 64 + 2 l32,
                 // 65 + 2 l32 for 8-byte cells): one 16-byte store per row, or two
-                const uint32_t lane_off = halfe * 4u * kSlab + (sizeof(Cell) == 4 ? 4u : 2u) * l32e;
+                const uint32_t lane_off = halfe * 4u * kSlab + (sizeof(Cell) <= 4 ? 4u : 2u) * l32e;
                 const uint32_t lane_off_b = lane_off * (uint32_t)sizeof(Cell);
                 const float *const rt = rtab32 + halfe * 16u, *const ct = ctab32 + l32e * 4u;
                 const uint32_t grp0 = roff / kGroup;   // first 8-row group of this wave's rows inside the unit (scalar)
@@ -1043,7 +1054,7 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                 // kDeg forces the cells of degenerate rows / columns to the int-0 code (one v_cndmask per cell)
                 auto steps = [&](auto small_c, auto deg_c) -> bool {
                 constexpr bool kDeg = decltype(deg_c)::value;
-                const uint32_t forced = sizeof(Cell) == 4 ? ((uint32_t)LDX_K16_INT0 << 16 | LDX_K16_INT0) : 0x80000000u;   // int 0, int 0
+                [[maybe_unused]] const uint32_t forced = sizeof(Cell) == 4 ? ((uint32_t)LDX_K16_INT0 << 16 | LDX_K16_INT0) : 0x80000000u;   // int 0, int 0
                 // LDX_STEP_UNROLL steps per trip of the loop (1, 2, 4, 8 or 16; the rows of a step are (e & 3) + 8 (e >> 2) + 32 m:
                 // unrolled by 4 the row inside its group of eight is static -- LDS and store offsets become immediates, the
                 // scalar address arithmetic happens once per four steps --, unrolled by 16 the accumulator index is static too)
@@ -1074,43 +1085,60 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
                     F32Row rows[MM];
                     load_rows(e, rows);
 #endif
+                    constexpr int kOne = cell_measure<Cell>::value;   // >= 0: a one-measure format (2-byte cells)
                     Cell cell[4 * MM];
+                    uint32_t cellw[2 * MM];   // one-measure formats: a row's four cells as two words
                     float wmax = 0.0f, ymin = 1.0f;
 #pragma unroll
                     for (int g = 0; g < MM; ++g) {   // four interleaved chains at a time: (m, tt) = (g, 0..3)
                         float c4[4];
                         F32Row r4[4];
-                        Cell o4[4];
 #pragma unroll
                         for (int tt = 0; tt < 4; ++tt) {
                             c4[tt] = acc[g][tt][e];
                             r4[tt] = rows[g];
                         }
-                        ld_multi_f32<4, Cell, decltype(small_c)::value, !decltype(small_c)::value>(c4, fc32, r4, cols, o4, wmax, ymin, cal);
+                        uint64_t rowmask = 0;
                         if constexpr (kDeg) {   // this step's two rows of tile g: lanes 0-31 hold row ri, lanes 32-63 row ri + 4
                             const uint32_t ri0 = 32u * g + (e & 3) + 8u * (e >> 2);
-                            const uint64_t rowmask = (((rdeg >> ri0) & 1ull) ? 0x00000000FFFFFFFFull : 0ull) |
-                                                     (((rdeg >> (ri0 + 4u)) & 1ull) ? 0xFFFFFFFF00000000ull : 0ull);
+                            rowmask = (((rdeg >> ri0) & 1ull) ? 0x00000000FFFFFFFFull : 0ull) |
+                                      (((rdeg >> (ri0 + 4u)) & 1ull) ? 0xFFFFFFFF00000000ull : 0ull);
+                        }
+                        if constexpr (kOne >= 0) {
+                            uint32_t b4[4];
+                            ld_multi_f32_one<4, kOne, decltype(small_c)::value, !decltype(small_c)::value>(c4, fc32, r4, cols, b4, wmax, ymin, cal);
+                            if constexpr (kDeg) {
 #pragma unroll
-                            for (int tt = 0; tt < 4; ++tt) {
-                                const uint64_t m = rowmask | colmask[tt];
-                                if constexpr (sizeof(Cell) == 4) {
-                                    o4[tt] = __builtin_bit_cast(Cell, select_lanes(__builtin_bit_cast(uint32_t, o4[tt]), forced, m));
-                                } else {
-                                    const v2u w = __builtin_bit_cast(v2u, o4[tt]);
-                                    o4[tt] = __builtin_bit_cast(Cell, v2u{select_lanes(w.x, forced, m), select_lanes(w.y, forced, m)});
+                                for (int tt = 0; tt < 4; ++tt) b4[tt] = select_lanes(b4[tt], (uint32_t)LDX_K16_INT0, rowmask | colmask[tt]);
+                            }
+                            // the cells are the low halves of 2^23 + k: two per byte permute
+                            cellw[2 * g] = __builtin_amdgcn_perm(b4[1], b4[0], 0x05040100u);
+                            cellw[2 * g + 1] = __builtin_amdgcn_perm(b4[3], b4[2], 0x05040100u);
+                        } else {
+                            Cell o4[4];
+                            ld_multi_f32<4, Cell, decltype(small_c)::value, !decltype(small_c)::value>(c4, fc32, r4, cols, o4, wmax, ymin, cal);
+                            if constexpr (kDeg) {
+#pragma unroll
+                                for (int tt = 0; tt < 4; ++tt) {
+                                    const uint64_t m = rowmask | colmask[tt];
+                                    if constexpr (sizeof(Cell) == 4) {
+                                        o4[tt] = __builtin_bit_cast(Cell, select_lanes(__builtin_bit_cast(uint32_t, o4[tt]), forced, m));
+                                    } else {
+                                        const v2u w = __builtin_bit_cast(v2u, o4[tt]);
+                                        o4[tt] = __builtin_bit_cast(Cell, v2u{select_lanes(w.x, forced, m), select_lanes(w.y, forced, m)});
+                                    }
                                 }
                             }
-                        }
 #pragma unroll
-                        for (int tt = 0; tt < 4; ++tt) cell[g * 4 + tt] = o4[tt];
+                            for (int tt = 0; tt < 4; ++tt) cell[g * 4 + tt] = o4[tt];
+                        }
                     }
                     const bool sure = ((wmax < fc32.tol) & (ymin > 0.0f)) | ((ablate & 1024) != 0);   // tuning: 1024 = never park
 #ifdef LDX_AB_NOSTORE   // tuning: the cells are computed and kept alive, not stored (results missing)
                     if (sure) {
                         uint32_t x = 0;
 #pragma unroll
-                        for (int q8 = 0; q8 < 4 * MM; ++q8) { if constexpr (sizeof(Cell) == 4) x ^= __builtin_bit_cast(uint32_t, cell[q8]); else x ^= (uint32_t)__builtin_bit_cast(unsigned long long, cell[q8]) ^ (uint32_t)(__builtin_bit_cast(unsigned long long, cell[q8]) >> 32); }
+                        for (int q8 = 0; q8 < 4 * MM; ++q8) { if constexpr (sizeof(Cell) == 2) x ^= cellw[q8 / 2]; else if constexpr (sizeof(Cell) == 4) x ^= __builtin_bit_cast(uint32_t, cell[q8]); else x ^= (uint32_t)__builtin_bit_cast(unsigned long long, cell[q8]) ^ (uint32_t)(__builtin_bit_cast(unsigned long long, cell[q8]) >> 32); }
                         asm volatile("" : : "v"(x));
                     }
                     if (false) {
@@ -1120,7 +1148,8 @@ triangle_mfma_kernel(const uint4 *__restrict__ alt, const double *__restrict__ f
 #pragma unroll
                         for (int m = 0; m < MM; ++m) {   // groups of 8 rows: 4 m + e / 4 of a whole unit, 4 hsel + e / 4 of a half-height one
                             Cell *const row = ubase + ((4u * m + grp0 + (e >> 2)) * LDX_UNIT_PAIRS + (e & 3) * kSlab);   // scalar
-                            store_cells4_saddr(row, lane_off_b, cell[m * 4 + 0], cell[m * 4 + 1], cell[m * 4 + 2], cell[m * 4 + 3]);
+                            if constexpr (kOne >= 0) store_words2_saddr(row, lane_off_b, cellw[2 * m], cellw[2 * m + 1]);
+                            else store_cells4_saddr(row, lane_off_b, cell[m * 4 + 0], cell[m * 4 + 1], cell[m * 4 + 2], cell[m * 4 + 3]);
                         }
                     }
 #ifdef LDX_AB_OLD_BALLOT
@@ -1626,6 +1655,17 @@ int triangle_mfma(const void *alt, const double *fa, const double *fr, const dou
                                                out_raw, out_n11, sched, s)                                          \
                : launch_mfma<R, N, false, CELL>(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end, (CELL *)out,   \
                                                 out_raw, out_n11, sched, s)
+    if (out_format == LDX_OUT_K16_RSQ || out_format == LDX_OUT_K16_DPRIME) {   // one measure, 2-byte cells: the FP4 kernel only
+        if (!fp4) {
+            set_error("the one-measure cell formats run on the FP4 or the popcount kernel, not on the int8 matrix kernel");
+            return LDX_E_UNSUPPORTED;
+        }
+        if (out_format == LDX_OUT_K16_RSQ)
+            return launch_mfma<false, false, true, ldx_k16r>(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end, (ldx_k16r *)out,
+                                                            nullptr, nullptr, sched, s);
+        return launch_mfma<false, false, true, ldx_k16d>(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end, (ldx_k16d *)out,
+                                                        nullptr, nullptr, sched, s);
+    }
     if (out_format == LDX_OUT_K16) {   // no unrounded output beside the 4-byte cells (ldx_triangle_ex_dev checks)
         if (out_n11) LDX_GO(false, true, ldx_k16);
         LDX_GO(false, false, ldx_k16);

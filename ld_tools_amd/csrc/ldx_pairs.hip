@@ -309,14 +309,18 @@ __device__ inline float dense_value(const ldx_ld32 &c, int measure, double *k)
     *k = v != v ? __builtin_inf() : __builtin_rint((double)v * 1e4);
     return v;
 }
-__device__ inline float dense_value(const ldx_k16 &c, int measure, double *k)
+__device__ inline float dense_value_u16(uint32_t u, double *k)
 {
-    const uint32_t u = measure == LDX_MEASURE_RSQ ? c.r_square : c.d_prime;
     if (u & LDX_K16_INT0) { *k = 0.0; return -0.0f; }
     if (u == LDX_K16_BIG) { *k = __builtin_inf(); return __uint_as_float(LDX_LD32_BIG_BITS); }
     *k = (double)u;
     return (float)((double)u * 1e-4);
 }
+__device__ inline float dense_value(const ldx_k16 &c, int measure, double *k)
+{
+    return dense_value_u16(measure == LDX_MEASURE_RSQ ? c.r_square : c.d_prime, k);
+}
+__device__ inline float dense_value(const ldx_k16one &c, int, double *k) { return dense_value_u16(c.value, k); }   // (the host checked the measure)
 
 template <typename Cell>
 __global__ void triangle_dense_kernel(const Cell *__restrict__ strips, uint32_t n_snps, uint32_t n_slabs,
@@ -454,8 +458,10 @@ extern "C" int ldx_triangle_ex_dev(const void *alt, const double *fa, const doub
     LDX_REQUIRE(!workspace || ((uintptr_t)workspace & 255u) == 0, "workspace must be 256-byte aligned");
     LDX_REQUIRE(alt && fa && fr && q && out, "null pointer");
     LDX_REQUIRE(known_path(path), "unknown path");
-    LDX_REQUIRE(out_format == LDX_OUT_LD32 || out_format == LDX_OUT_K16, "unknown output format");
+    const bool one_measure = out_format == LDX_OUT_K16_RSQ || out_format == LDX_OUT_K16_DPRIME;
+    LDX_REQUIRE(out_format == LDX_OUT_LD32 || out_format == LDX_OUT_K16 || one_measure, "unknown output format");
     LDX_REQUIRE(out_format == LDX_OUT_LD32 || !out_raw, "out_raw needs LDX_OUT_LD32");
+    LDX_REQUIRE(!one_measure || !out_n11, "the one-measure formats take no side output");
     LDX_REQUIRE(n_snps >= 1 && n_hap >= 1, "bad shape");
     if (n_hap > LDX_MAX_HAPS) {
         set_error("ldx_triangle_dev: n_hap %u > LDX_MAX_HAPS %u", n_hap, LDX_MAX_HAPS);
@@ -476,6 +482,10 @@ extern "C" int ldx_triangle_ex_dev(const void *alt, const double *fa, const doub
         if (path != LDX_PATH_AUTO) return LDX_E_UNSUPPORTED;   // an explicit matrix-pipe path: say so (message set)
         // AUTO and a bit plane of 4 GiB or more: the popcount kernel gives the very same cells
     }
+    if (out_format == LDX_OUT_K16_RSQ)
+        return launch_triangle<false, false>(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end, (ldx_k16r *)out, out_raw, out_n11, s);
+    if (out_format == LDX_OUT_K16_DPRIME)
+        return launch_triangle<false, false>(alt, fa, fr, q, n_snps, n_hap, unit_begin, unit_end, (ldx_k16d *)out, out_raw, out_n11, s);
     if (out_format == LDX_OUT_K16) {
         ldx_k16 *o = (ldx_k16 *)out;
         if (out_n11)
@@ -559,13 +569,19 @@ extern "C" int ldx_triangle_dense_ex_dev(const void *strips, int strips_format, 
                                          size_t ld, void *stream)
 {
     LDX_REQUIRE(strips && dense, "null pointer");
-    LDX_REQUIRE(strips_format == LDX_OUT_LD32 || strips_format == LDX_OUT_K16, "unknown cell format");
+    LDX_REQUIRE(strips_format == LDX_OUT_LD32 || strips_format == LDX_OUT_K16 || strips_format == LDX_OUT_K16_RSQ ||
+                    strips_format == LDX_OUT_K16_DPRIME, "unknown cell format");
+    LDX_REQUIRE(strips_format != LDX_OUT_K16_RSQ || measure == LDX_MEASURE_RSQ, "the strips hold r_square only");
+    LDX_REQUIRE(strips_format != LDX_OUT_K16_DPRIME || measure == LDX_MEASURE_DPRIME, "the strips hold d_prime only");
     LDX_REQUIRE(row_begin <= row_end && row_end <= n_snps && ld >= n_snps, "bad shape");
     LDX_REQUIRE(measure == LDX_MEASURE_RSQ || measure == LDX_MEASURE_DPRIME, "bad measure");
     if (row_begin == row_end) return LDX_OK;
     const dim3 grid((n_snps + 255u) / 256u, row_end - row_begin);
     const double kt = has_thres ? thres_to_k(thres) : 0.0;
-    if (strips_format == LDX_OUT_K16)
+    if (strips_format == LDX_OUT_K16_RSQ || strips_format == LDX_OUT_K16_DPRIME)
+        triangle_dense_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const ldx_k16one *)strips, n_snps, ldx::n_slabs(n_snps),
+                                                                    measure, has_thres, kt, row_begin, row_end, dense, ld);
+    else if (strips_format == LDX_OUT_K16)
         triangle_dense_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const ldx_k16 *)strips, n_snps, ldx::n_slabs(n_snps),
                                                                     measure, has_thres, kt, row_begin, row_end, dense, ld);
     else

@@ -7,6 +7,7 @@ from typing import List, Optional, Sequence
 
 import numpy as np
 
+from .._lib import ONE_MEASURE_FMT
 from ..ops import ld_triangle
 from ..panel import PackedPanel
 from .ingest import RaggedGenotypesError, codes_matrix, find_record, k_to_python, sample_genotypes
@@ -57,7 +58,9 @@ def triangle_matrix(vcf, chrom, chrom_rows: Sequence[Sequence], sample_names: Se
         alt_freqs = [round(list(g).count(1) / len(g), 4) for g in genotypes]
         return TriangleMatrix(chrom, rs_ids, poss, ld_two_dim, alleles, types, alt_freqs)
     panel = PackedPanel.from_codes(codes)
-    res = ld_triangle(panel, fmt="k16")                               # 4-byte cells: k and the int-0 mark, lossless
+    # the table holds ONE measure (ld_triangle.py:223-230): 2-byte cells -- k and the int-0 mark of that measure, lossless;
+    # the kernel skips the other value's arithmetic
+    res = ld_triangle(panel, fmt=ONE_MEASURE_FMT[ld_measure])
     dense, fixes = res.dense_values(ld_measure, ld_low_thres)        # -0.0 = the template's / a computed int 0
     flat = k_to_python(dense, fixes)
     ld_two_dim = [flat[r * n:(r + 1) * n] for r in range(n)]

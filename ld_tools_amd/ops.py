@@ -50,10 +50,11 @@ def get_area_path() -> str:
 class TriangleResult:
     """Strip-packed lower triangle of one panel (layout: include/ldx.h, "Triangle work units").
 
-    The cells are in ONE of the two formats of include/ldx.h: ``ld32`` (float32 nearest to k / 10^4, -0.0 = the
-    reference's int 0, 8 bytes per pair) or ``k16`` (k itself in 15 bits + an int-0 bit, 4 bytes per pair).  Values a
-    format cannot hold (>= 1024 / >= 3.2767: only with missing codes) are escape cells; ``exact()`` /
-    ``dense_values()`` resolve them through ldx_ld_pairs_dev, so nothing is ever returned inexact.
+    The cells are in ONE of the formats of include/ldx.h: ``ld32`` (float32 nearest to k / 10^4, -0.0 = the
+    reference's int 0, 8 bytes per pair), ``k16`` (k itself in 15 bits + an int-0 bit, 4 bytes per pair) or -- one measure
+    only, 2 bytes per pair, what a table writer needs (ld_triangle.py:223-230,344-360 print ONE measure) -- ``k16r`` /
+    ``k16d`` (the r_square / d_prime half of k16).  Values a format cannot hold (>= 1024 / >= 3.2767: only with missing
+    codes) are escape cells; ``dense_values()`` resolves them through ldx_ld_pairs_dev, so nothing is ever returned inexact.
     """
 
     n_snps: int
@@ -64,16 +65,22 @@ class TriangleResult:
     n11: Optional[torch.Tensor] = None       # int32   [(units)*1024]     alt/alt haplotype counts
     k16: Optional[torch.Tensor] = None       # int16   [(units)*1024, 2]  bit patterns of the uint16 cells
     panel: Optional[PackedPanel] = None      # the panel the result came from (resolves escape cells)
+    k16one: Optional[torch.Tensor] = None    # int16   [(units)*1024]     one measure's uint16 cells (fmt k16r / k16d)
+    one_fmt: Optional[str] = None            # "k16r" / "k16d" when k16one is set
     ws: Optional[torch.Tensor] = None        # the matrix kernel's pass-scheduler workspace (include/ldx.h, ldx_triangle_ex_dev):
                                              # zeroed once here, re-armed by every launch; one per result buffer, because two
                                              # launches that may overlap write different buffers
 
     @property
     def fmt(self) -> str:
+        if self.k16one is not None:
+            return self.one_fmt
         return "ld32" if self.ld32 is not None else "k16"
 
     @property
     def cells(self) -> torch.Tensor:
+        if self.k16one is not None:
+            return self.k16one
         return self.ld32 if self.ld32 is not None else self.k16
 
     def cell_index(self, rows, cols) -> np.ndarray:
@@ -93,6 +100,11 @@ class TriangleResult:
         """(k int64 [m, 2], int0 bool [m, 2], escape bool [m, 2]) of the cells at flat indices ``idx`` (host arrays);
         k of an escape cell is -1."""
         ix = torch.as_tensor(np.asarray(idx, dtype=np.int64), device=self.cells.device)
+        if self.k16one is not None:          # one measure: arrays of shape [m, 1]
+            u = self.k16one[ix].cpu().numpy().view(np.uint16).astype(np.int64).reshape(-1, 1)
+            int0 = (u & _lib.K16_INT0) != 0
+            esc = u == _lib.K16_BIG
+            return np.where(esc, -1, np.where(int0, 0, u)), int0, esc
         if self.ld32 is not None:
             v = self.ld32[ix].cpu().numpy()
             esc = np.isnan(v)
@@ -113,6 +125,8 @@ class TriangleResult:
         """
         if self.unit_begin != 0 or self.unit_end != lib.ldx_triangle_units(self.n_snps):
             raise _lib.LdxError("dense() needs an unsharded TriangleResult")
+        if self.k16one is not None and _lib.ONE_MEASURE[self.one_fmt] != measure:
+            raise _lib.LdxError(f"this result holds {_lib.ONE_MEASURE[self.one_fmt]} only (format {self.one_fmt})")
         r0, r1 = rows if rows is not None else (0, self.n_snps)
         out = torch.empty((r1 - r0, self.n_snps), dtype=torch.float32, device=self.cells.device)
         check(lib.ldx_triangle_dense_ex_dev(self.cells.data_ptr(), _lib.FORMATS[self.fmt], self.n_snps,
@@ -149,8 +163,9 @@ def ld_triangle(panel: PackedPanel, unit_range: Optional[Tuple[int, int]] = None
 
     ``unit_range`` restricts the work to a contiguous slice of the unit list (multi-GPU sharding);
     ``out`` re-uses the buffers of a previous result of the same shape (benchmark loops); ``fmt`` picks the cell
-    format ('ld32': 8 bytes per pair, 'k16': 4 bytes per pair); ``path`` overrides the process-wide kernel choice
-    ('fp4', 'mfma', 'popcount') for this call.
+    format ('ld32': 8 bytes per pair, 'k16': 4 bytes per pair, 'k16r' / 'k16d': ONE measure, 2 bytes per pair -- the kernel
+    then skips the other value's arithmetic); ``path`` overrides the process-wide kernel choice ('fp4', 'mfma', 'popcount')
+    for this call.
     """
     total = panel.n_units
     u0, u1 = (0, total) if unit_range is None else unit_range
@@ -159,14 +174,18 @@ def ld_triangle(panel: PackedPanel, unit_range: Optional[Tuple[int, int]] = None
     dev = panel.device
     if fmt not in _lib.FORMATS:
         raise _lib.LdxError(f"unknown cell format {fmt!r}")
-    if fmt == "k16" and want_raw:
+    if fmt != "ld32" and want_raw:
         raise _lib.LdxError("the unrounded output travels with the ld32 format only")
+    if fmt in _lib.ONE_MEASURE and want_n11:
+        raise _lib.LdxError("the one-measure formats take no side output")
     if out is None:
         out = TriangleResult(panel.n_snps, u0, u1,
                              torch.empty((cells, 2), dtype=torch.float32, device=dev) if fmt == "ld32" else None,
                              torch.empty((cells, 2), dtype=torch.float64, device=dev) if want_raw else None,
                              torch.empty(cells, dtype=torch.int32, device=dev) if want_n11 else None,
-                             torch.empty((cells, 2), dtype=torch.int16, device=dev) if fmt == "k16" else None)
+                             torch.empty((cells, 2), dtype=torch.int16, device=dev) if fmt == "k16" else None,
+                             k16one=torch.empty(cells, dtype=torch.int16, device=dev) if fmt in _lib.ONE_MEASURE else None,
+                             one_fmt=fmt if fmt in _lib.ONE_MEASURE else None)
     elif (out.n_snps, out.unit_begin, out.unit_end, out.fmt) != (panel.n_snps, u0, u1, fmt):
         raise _lib.LdxError("ld_triangle: `out` has a different shape or format")
     out.panel = panel

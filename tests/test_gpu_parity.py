@@ -486,6 +486,44 @@ def test_triangle_k16_cells_equal_ld32_cells(gpu, path):
     assert a.dense_values("r_square")[1][(1, 0)] == 4080.4507 and a.dense_values("d_prime")[1][(1, 0)] == 4948.0
 
 
+@pytest.mark.parametrize("n,h,kw", [(10000, 5008, {}), (50000, 1008, {}), (3000, 300, dict(miss=0.01)),
+                                    (6000, 1008, dict(mono=0.3, miss=0.001, miss_rows=0.2)), (700, 5008, {})])
+def test_one_measure_cells_equal_the_two_value_cells(gpu, n, h, kw):
+    """the one-measure formats (2 bytes per pair: what a table writer needs, ld_triangle.py:223-230,
+    344-360 print ONE measure) skip the other value's arithmetic in the fp32 tier.  For EVERY pair of configs[1] and
+    configs[4] (and panels with missing codes, monomorphic SNPs, all-short passes) the r_square cell equals the r_square half
+    of the two-value kernel's 4-byte cell and the d_prime cell its d_prime half -- FP4 kernel and popcount kernel -- escapes
+    and int-0 marks included."""
+    import torch
+    from ld_tools_amd import PackedPanel, ld_triangle, synth
+
+    p = PackedPanel.from_codes(synth.synth_codes_device(n, h, seed=synth.BENCH_SEED, **kw))
+    both = ld_triangle(p, fmt="k16", path="fp4")
+    for col, fmt in ((0, "k16r"), (1, "k16d")):
+        one = ld_triangle(p, fmt=fmt, path="fp4")
+        assert one.k16one.dtype == torch.int16 and one.k16one.numel() == both.k16.shape[0]
+        assert torch.equal(one.k16one, both.k16[:, col].contiguous()), (fmt, "fp4")
+        if n <= 10000:
+            pop = ld_triangle(p, fmt=fmt, path="popcount")
+            assert torch.equal(pop.k16one, one.k16one), (fmt, "popcount")
+            del pop
+        del one
+    # the int8 matrix kernel does not carry these formats and says so; side outputs are refused
+    from ld_tools_amd import _lib
+    with pytest.raises(_lib.LdxError):
+        ld_triangle(p, fmt="k16r", path="mfma")
+    with pytest.raises(_lib.LdxError):
+        ld_triangle(p, fmt="k16d", want_n11=True)
+    if n <= 3000:   # dense() and its escape resolution (values >= 3.2767 only arise with missing codes)
+        for measure, fmt in (("r_square", "k16r"), ("d_prime", "k16d")):
+            one = ld_triangle(p, fmt=fmt)
+            d1, f1 = one.dense_values(measure, 0.2)
+            d2, f2 = both.dense_values(measure, 0.2)
+            assert np.array_equal(d1.view(np.int32), d2.view(np.int32)) and f1 == f2
+            with pytest.raises(_lib.LdxError):
+                one.dense("d_prime" if measure == "r_square" else "r_square")
+
+
 def test_ld_pairs_exact_for_any_magnitude(gpu):
     from ld_tools_amd import PackedPanel, ops
     from oracle import c_oracle
