@@ -14,8 +14,10 @@
 //     same speed) that lives in the CALLER's workspace (ldx_triangle_workspace_bytes; the band: ldx_area_workspace_bytes)
 //     -- the library keeps no per-stream or per-process scheduling state (round 6).
 //   * B side (the 128 j-rows, shared by the 4 waves): per K-block (256 haplotypes, FP4; 128, int8) the workgroup expands
-//     the j-tile's bits ONCE into an LDS image (double-buffered for the triangle, triple-buffered for the ld_area band);
-//     one LDS-only barrier per K-block.  Fragments are plain ds_read_b128.
+//     the j-tile's bits ONCE into a double-buffered LDS image; one LDS-only barrier per K-block.  Fragments are plain
+//     ds_read_b128.  (Round 6 built and measured two barrier-free K loops for the ld_area band -- a triple-buffered image
+//     with progress flags, and waves that expand the j-rows themselves, also as fully independent workers: slower / flat;
+//     patches, A/B logs, stamps and counters under profiles/r06/, the account in HISTORY.md.)
 //   * A side (a wave's own 64 rows): each lane loads the 16 bytes of "its" row per K-block (row = lane % 32 of each 32-row
 //     tile, lane half = chunk of the K-block) three blocks ahead with hand-issued global loads (hand-counted s_waitcnt
 //     vmcnt) and expands them in registers.
@@ -1760,9 +1762,10 @@ __global__ void __launch_bounds__(1024) area_band_plan_kernel(const int64_t *__r
     }
     // Ticket order (ticket -> pass).  The kernel hands the passes out per XCD: eight contiguous ranges of TILES, walked in
     // position order for the L2s.  A tile's FIRST pass holds its diagonal units -- where the hits are, i.e. where the full
-    // fp64 epilogue runs (round 4 stamps: epilogue 97k cycles against 11k for the other passes) -- and in plain tile order a
-    // range ended with such passes while the rest of the chip idled (wave slots 76 % busy).  So inside each range all first
-    // passes come first, in tile order, then the other passes in tile order: the launch ends with short items.
+    // fp64 epilogue runs (stamps: epilogue ~38k cycles against 11k for the other passes) -- and in plain tile order a range
+    // ended with such passes while the rest of the chip idled.  So a tile's first pass is handed out EARLY: kLead tiles
+    // ahead of the tile whose other passes are being handed out (one sweep per range: the formula is at the loop below);
+    // round 4's order -- all first passes of a range, then all the others: two sweeps -- is kept under LDX_AB_FIRST_FIRST.
     if (!order) return;   // (a panel whose full triangle has more than kOrderCap passes: plain tile order)
     __threadfence_block();
     block_sync();

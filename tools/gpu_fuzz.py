@@ -6,7 +6,8 @@
 Every round draws a panel shape (SNPs 2..9000, haplotypes 16..6000, a missing-code rate, sometimes monomorphic or
 all-missing rows), packs it, and compares
   * ld_triangle: 'fp4' and 'mfma' against 'popcount', both cell formats, with and without the n11 plane, on the whole
-    triangle and on a random unit range, each matrix-pipe launch repeated (the second launch into a poisoned buffer);
+    triangle and on a random unit range, each matrix-pipe launch repeated (the second launch into a poisoned buffer); the
+    one-measure cells (round 6) against the halves of the 4-byte cells; one panel in five with 5 % or 30 % monomorphic SNPs;
   * ld_pairs, pair_counts and the fused drop-in calc_ld on random pairs against the triangle's cells and n11 plane;
   * ld_area: the three kernels' ordered hit lists for a random flank / measure / threshold / query subset;
   * (one round in twenty) a HIP graph of two to five matrix-kernel launches into two alternating result buffers, some of
@@ -46,12 +47,15 @@ def run(budget: float = 120.0, seed: int = 1, progress: float = 0.0) -> str:
         h = int(rng.choice([rng.randint(16, 300), rng.randint(300, 1100), rng.choice([1008, 2504, 5008, 5096]), rng.randint(1100, 6000)]))
         miss = float(rng.choice([0.0, 0.0, 0.002, 0.05]))
         seed = int(rng.randint(1, 1 << 30))
-        codes = synth.synth_codes_device(n, h, seed=seed, miss=miss)
+        # (round 6) sometimes a panel that is far from "all ordinary": a share of monomorphic SNPs, missing codes in a share of rows
+        mono = float(rng.choice([0.0, 0.0, 0.0, 0.05, 0.3]))
+        mrows = float(rng.choice([1.0, 1.0, 0.2]))
+        codes = synth.synth_codes_device(n, h, seed=seed, miss=miss, mono=mono, miss_rows=mrows)
         if rng.rand() < 0.3:                                   # degenerate rows: monomorphic ALT / REF, all missing
             for r in rng.randint(0, n, size=3):
                 codes[int(r), :h] = int(rng.choice([0, 1, 2]))
         p = PackedPanel.from_codes(codes)
-        tag = f"n={n} h={h} miss={miss} seed={seed}"
+        tag = f"n={n} h={h} miss={miss} mono={mono} miss_rows={mrows} seed={seed}"
         for fmt in ("k16", "ld32"):
             view = torch.int16 if fmt == "k16" else torch.int32
             want_n11 = bool(rng.rand() < 0.3)
@@ -71,6 +75,12 @@ def run(budget: float = 120.0, seed: int = 1, progress: float = 0.0) -> str:
                     got.cells.view(view).fill_(-1)
                     ld_triangle(p, fmt=fmt, path=path, want_n11=want_n11, unit_range=ur, out=got)
             pairs += ref.cells.shape[0]
+            if fmt == "k16" and ur is None and rng.rand() < 0.5:   # (round 6) the one-measure cells against the halves of the 4-byte cells
+                for col, f1 in ((0, "k16r"), (1, "k16d")):
+                    for path in ("fp4", "popcount"):
+                        one = ld_triangle(p, fmt=f1, path=path)
+                        if not torch.equal(one.k16one, ref.k16[:, col].contiguous()):
+                            fail(f"ld_triangle {path} {f1} against the {fmt} cells: {tag}")
         # launches chained by a HIP graph instead of a stream (round 5: such launches, into alternating result buffers, lost
         # their tickets): a few launches of either matrix kernel, sometimes forked onto a side stream, replayed twice
         if graphs < 2000 and rng.rand() < 0.05:
