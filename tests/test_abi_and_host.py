@@ -223,6 +223,15 @@ def test_geometry_helpers():
     # cells >= pairs, with less than 4 % padding at the bench size
     cells = L.ldx_triangle_units(10000) * 1024
     assert 10000 * 9999 // 2 <= cells < 1.04 * 10000 * 9999 // 2
+    # round 6: the matrix kernel's pass scheduler lives in a caller-owned workspace of a fixed, 256-byte-granular size
+    assert L.ldx_triangle_workspace_bytes() % 256 == 0 and 256 <= L.ldx_triangle_workspace_bytes() <= 1 << 16
+    # ... and a rank's share of the work in PAIRS (bench.py's per_rank record): the unit ranges tile the triangle exactly
+    for n, world in ((300, 3), (1000, 4), (10000, 8)):
+        parts = dist.unit_partition(n, world)
+        pairs = [dist.pairs_in_units(n, a, b) for a, b in parts]
+        assert sum(pairs) == n * (n - 1) // 2 and max(b - a for a, b in parts) - min(b - a for a, b in parts) <= 1
+        rows, _ = dist.unit_cells(n, *parts[1])
+        assert len(rows) == pairs[1]
 
 
 def test_unit_cell_order_is_a_permutation_and_matches_the_library():
@@ -232,9 +241,14 @@ def test_unit_cell_order_is_a_permutation_and_matches_the_library():
 
     r, c = np.meshgrid(np.arange(8), np.arange(128), indexing="ij")
     L = _lib.lib
-    for fmt in ("k16", "ld32"):
+    for fmt in ("k16", "ld32", "k16r", "k16d"):
         off = _lib.cell_offset(r, c, fmt)
         assert sorted(off.ravel().tolist()) == list(range(1024))
+        if fmt in _lib.ONE_MEASURE:        # the one-measure formats (round 6) order their 2-byte cells like the 4-byte format
+            assert np.array_equal(off, _lib.cell_offset(r, c, "k16")) and _lib.ONE_MEASURE_FMT[_lib.ONE_MEASURE[fmt]] == fmt
+            for n, i, j in ((10000, 9999, 3), (300, 299, 298), (100000, 77777, 12345)):
+                assert L.ldx_triangle_cell_index(n, i, j, _lib.FORMATS[fmt]) == L.ldx_triangle_cell_index(n, i, j, _lib.FORMATS["k16"])
+            continue
         # the four columns one lane of the matrix kernel holds (l, l + 32, l + 64, l + 96) are adjacent: all four (4-byte cells)
         # or in two pairs (8-byte cells), so that the lane writes 16 bytes per store
         for row in range(8):
