@@ -153,3 +153,25 @@ def test_bench_four_ranks_one_card_configs3():
     pairs = [x["pairs"] for x in pr]
     assert sum(pairs) == 100000 * 99999 // 2 and max(pairs) / min(pairs) - 1.0 < 0.006, pairs
     assert all(x["kernel_ms"] > 0 and x["exchange_ms_per_step"] is not None for x in pr)
+
+
+@pytest.mark.gpu
+def test_bench_one_rank_rccl_group():
+    """The sharded path over RCCL itself, as far as one card goes: `bench.py --force-dist` builds a ONE-rank nccl (= RCCL)
+    process group and runs the shard pack -> all-gather -> unit-range kernel steps through it -- the code of an N-GPU run with
+    N = 1.  The line must say it was an RCCL group, carry the seven timed regions and the per-rank record."""
+    import json
+
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--force-dist", "--steps", "3", "--warmup", "1", "--snps", "6000",
+                        "--settle-steps", "2", "--no-cpu-baseline", "--no-other-workloads", "--no-extra-legs"],
+                       capture_output=True, text=True, timeout=500, env=env, cwd=str(ROOT))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    cfg = rec["config"]
+    assert cfg["rccl_ranks"] == 1 and cfg["backend"] == "nccl" and cfg["nccl_version"] not in (None, "unknown")
+    assert cfg["workload"] == "ld_triangle 6000x5008" and "popcount kernel" in cfg["launch"]
+    assert len(rec["ms_per_step_runs"]) == 7 and rec["ms_per_step_min"] <= rec["ms_per_step"]
+    assert len(rec["per_rank"]) == 1 and rec["per_rank"][0]["pairs"] == 6000 * 5999 // 2 and rec["per_rank"][0]["kernel_ms"] > 0
