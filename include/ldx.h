@@ -213,7 +213,9 @@ int ldx_get_triangle_path(void);
  *   - the library keeps NO scheduling state of its own (no per-stream slots, no limit on streams or captured launches, no
  *     allocation, nothing to leak); a launch recorded under stream capture is like any other;
  *   - workspace = NULL is allowed: the passes are then dealt round-robin instead of drawn from the counter (identical
- *     cells; measured slower on panels of more than one round of passes) -- what ldx_triangle_dev does.
+ *     cells; measured 6.5-7.4 % slower on panels of more than one round of passes -- 10 000 x 5008, 40 000 x 5008,
+ *     50 000 x 1008 -- and 3 % faster below one round, profiles/r06/round_robin_without_workspace.log) -- what
+ *     ldx_triangle_dev does.
  * The popcount path ignores the workspace. */
 size_t ldx_triangle_workspace_bytes(void);
 int ldx_triangle_workspace_init_dev(void *workspace, size_t workspace_bytes, void *stream);   /* = hipMemsetAsync(workspace, 0, ...) */

@@ -1,6 +1,6 @@
 """ctypes binding of libldx.so (include/ldx.h).  No fallback: a missing library is an error.
 
-The library is built in-tree by ``python -m ld_tools_amd.build`` (``__graft_entry__.build()``
+The library is built in-tree by ``python ld_tools_amd/build.py`` (``__graft_entry__.build()``
 does it).  If it is missing and hipcc is present it is built on first import; if that fails,
 the import raises -- there is no CPU path in this package.
 """
@@ -52,7 +52,7 @@ class LdxError(RuntimeError):
 
 def _load() -> C.CDLL:
     # an existing library is loaded as it is (ranks of one job must not rebuild it under each other);
-    # `python -m ld_tools_amd.build` / __graft_entry__.build() refresh a stale one explicitly
+    # `python ld_tools_amd/build.py` / __graft_entry__.build() refresh a stale one explicitly
     if not LIB_PATH.exists():
         try:
             _build.build(verbose=False)
@@ -60,7 +60,7 @@ def _load() -> C.CDLL:
             if not LIB_PATH.exists():
                 raise ImportError(
                     f"ld_tools_amd: {LIB_PATH} is missing and could not be built ({exc}); "
-                    "run `python -m ld_tools_amd.build` on a machine with hipcc. "
+                    "run `python ld_tools_amd/build.py` on a machine with hipcc. "
                     "There is no CPU fallback.") from exc
     _share_hip_runtime()
     return C.CDLL(str(LIB_PATH))

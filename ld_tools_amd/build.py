@@ -1,6 +1,9 @@
 """Build libldx.so (the C-ABI HIP library) in-tree with hipcc for gfx950.
 
-    python -m ld_tools_amd.build [--force] [--save-temps]
+    python ld_tools_amd/build.py [--force] [--save-temps] [--out libldx_x.so] [-DLDX_...]
+
+(run the FILE, not `-m ld_tools_amd.build`: importing the package loads libldx.so first, and a library that is one ABI
+behind its header -- the very case a rebuild is for -- then fails the import before the build starts)
 
 The product never falls back to anything else: if the library is missing and cannot be built,
 importing ld_tools_amd._lib raises.

@@ -1159,7 +1159,12 @@ def test_triangle_on_a_thousand_raw_streams(gpu):
                                        panel.n_snps, panel.n_hap, 0, panel.n_units, path, _lib.FORMATS["k16"], dst.data_ptr(),
                                        None, None, ws.data_ptr(), ws_bytes, stream)
 
-    shared = workspace()
+    shared = torch.full((ws_bytes,), 0x5A, dtype=torch.uint8, device=p.device)     # garbage, then the library's own initialiser
+    assert lib.ldx_triangle_workspace_init_dev(shared.data_ptr(), ws_bytes, torch.cuda.current_stream().cuda_stream) == 0
+    assert lib.ldx_triangle_workspace_init_dev(shared.data_ptr(), ws_bytes - 1, None) < 0           # too small: refused
+    assert lib.ldx_triangle_ex_dev(p.alt.data_ptr(), p.fa.data_ptr(), p.fr.data_ptr(), p.q.data_ptr(), p.n_snps, p.n_hap, 0, p.n_units,
+                                   3, _lib.FORMATS["k16"], out.data_ptr(), None, None, shared.data_ptr() + 8, ws_bytes, None) < 0   # misaligned
+    torch.cuda.synchronize()
     for k in range(1000):
         st = ctypes.c_void_p()
         assert hip.hipStreamCreate(ctypes.byref(st)) == 0

@@ -8,6 +8,7 @@
     python tools/gpu_exp.py pack       # pack kernel bandwidth
     python tools/gpu_exp.py small      # configs[0] and other driver-sized tables: codes on the host -> ld_two_dim on the host
     python tools/gpu_exp.py calc       # the drop-in calc_ld pair by pair: microseconds per call
+    python tools/gpu_exp.py nows       # ldx_triangle_ex_dev with and without the pass scheduler's workspace (round-robin passes)
 """
 import json
 import sys
@@ -101,6 +102,40 @@ def main():
         scan.sort()
         out.update(end_to_end_ms=wall * 1e3, scan_ms_median=scan[len(scan) // 2], scan_ms_min=scan[0], hits=len(hits),
                    ordered_pairs=hits.n_pairs)
+    elif what == "nows":   # round 6: ticket counter in the caller's workspace against round-robin passes (workspace = NULL)
+        import statistics
+
+        from ld_tools_amd import _lib
+        from ld_tools_amd._lib import lib
+        res = {}
+        for n, h, reps in ((3000, 5008, 60), (10000, 5008, 60), (40000, 5008, 9), (50000, 1008, 9)):
+            p = PackedPanel.from_codes(synth.synth_codes_device(n, h))
+            o = ld_triangle(p, fmt="k16")
+            st = torch.cuda.current_stream().cuda_stream
+
+            def launch(ws):
+                rc = lib.ldx_triangle_ex_dev(p.alt.data_ptr(), p.fa.data_ptr(), p.fr.data_ptr(), p.q.data_ptr(), p.n_snps, p.n_hap, 0,
+                                             p.n_units, 3, _lib.FORMATS["k16"], o.cells.data_ptr(), None, None,
+                                             o.ws.data_ptr() if ws else None, o.ws.numel() if ws else 0, st)
+                assert rc == 0
+
+            for _ in range(max(3, reps // 3)):
+                launch(True)
+            torch.cuda.synchronize()
+            ms = {True: [], False: []}
+            for _ in range(reps):          # interleaved
+                for ws in (True, False):
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    launch(ws)
+                    b.record()
+                    torch.cuda.synchronize()
+                    ms[ws].append(a.elapsed_time(b))
+            res[f"{n}x{h}"] = {"workspace_ms": statistics.median(ms[True]), "round_robin_ms": statistics.median(ms[False]),
+                               "slower": statistics.median(ms[False]) / statistics.median(ms[True]) - 1.0}
+            del o, p
+            torch.cuda.empty_cache()
+        out.update(res)
     elif what == "tri100k":
         n, h = 100000, 5008
         p = PackedPanel.from_codes(synth.synth_codes_device(n, h))
