@@ -338,11 +338,11 @@ __device__ __forceinline__ double max_raw(double a, double b)
 //                   product of calc_ld.py:63-76 in each case), so y = 10^4 value < 12 700 fits the 15-bit cell and the
 //                   kClean variants' dropped guards (y < 10^7, k < 32767, no degenerate operand); a r >= (n - 1) / 2 replaces
 //                   a r >= n - 1 in the r^2 share of the reference's own error (f32_const doubles that term and more);
-//   kSnpDegenerate  a == 0 (whatever is missing), or r == 0 with a == n: calc_ld.py returns the int 0 for BOTH values
-//                   against ANY other SNP, whatever n11 is (:66-69 / :73-76: the bound is 0 or -0.0 -> ZeroDivisionError ->
-//                   d_prime = 0 -> :89-90 r_square = 0) -- and the alt/alt count of such a SNP with any SNP X is known (0,
-//                   resp. a_X), which lets the fp32 tier keep such rows / columns on its common path (f32_row below);
-//   kSnpOdd         everything else (many missing codes; r == 0 with a < n): parks, as every non-ordinary SNP did before.
+//   kSnpDegenerate  a == 0 or r == 0 (whatever is missing): calc_ld.py returns the int 0 for BOTH values against ANY other
+//                   SNP, whatever n11 is (:66-69 / :73-76: the bound is 0 or -0.0 -> ZeroDivisionError -> d_prime = 0 ->
+//                   :89-90 r_square = 0) -- and the alt/alt count of such a SNP with any SNP X is 0 (a == 0) or at most a_X,
+//                   which lets the fp32 tier keep such rows / columns on its common path (f32_row below);
+//   kSnpOdd         everything else (polymorphic with many missing codes): parks, as every non-ordinary SNP did before.
 constexpr int kSnpOrdinary = 0, kSnpDegenerate = 1, kSnpOdd = 2;
 __device__ __forceinline__ int snp_class(double fa, double fr, double n)
 {
@@ -350,8 +350,8 @@ __device__ __forceinline__ int snp_class(double fa, double fr, double n)
 #ifdef LDX_AB_R5CLASS   // tuning: rounds 1-5's rule -- ordinary iff polymorphic and complete, everything else parks
     return (a > 0.0 && r > 0.0 && a + r == n) ? kSnpOrdinary : kSnpOdd;
 #endif
-    if (a == 0.0 || (r == 0.0 && a == n)) return kSnpDegenerate;
-    return (r > 0.0 && 8.0 * (n - a - r) <= r) ? kSnpOrdinary : kSnpOdd;
+    if (a == 0.0 || r == 0.0) return kSnpDegenerate;
+    return 8.0 * (n - a - r) <= r ? kSnpOrdinary : kSnpOdd;
 }
 __device__ __forceinline__ bool fast_ordinary(double fa, double fr, double n) { return snp_class(fa, fr, n) == kSnpOrdinary; }
 
@@ -494,8 +494,9 @@ __host__ __device__ inline F32Const f32_const(double n)
 // kSnpDegenerate (round 6) stays on the common path.  Its cells are the int-0 code whatever the arithmetic says, so the
 // step loop FORCES them (one v_cndmask per cell under a scalar lane mask, only in units that hold such a SNP:
 // epilogue_f32, kDeg) and the table entries only have to keep the margin test quiet: a fake count A (1 for a == 0, n + 1
-// for a == n) makes  Dn = n c - A1 A2  a NEGATIVE NON-ZERO integer against every other entry -- c is 0 for an all-REF
-// SNP and a_X for an all-ALT one, so Dn = -A_X resp. a_X n - (n + 1) A_X = -a_X (ordinary X), -(n + 1), -(2n + 1) -- the
+// for r == 0) makes  Dn = n c - A1 A2  a NEGATIVE NON-ZERO number against every other entry -- c is 0 for a SNP without ALT
+// alleles and at most a_X for one without REF alleles, so Dn = -A_X resp. Dn <= a_X n - (n + 1) A_X = -a_X (ordinary X),
+// -(n + 1), -(2n + 1); where |Dn| exceeds 2^24 the two fma round, which cannot reach zero or change the sign -- the
 // sign picks x = ra, y = rr;  ra = eps, rr = 0, s = 2^-20  give tiny positive  y_r = (Dn s1 s2)^2 < 0.01  and  y_d  (eps_r =
 // 2^-10 against an ordinary column: y_d = a_X eps_r fl(1 / a_X); eps_c = 2^-24 against an ordinary row: 10^4 eps_c; both:
 // <= (2n + 2) 2^-34): both round to 0 with a margin near 0, min y_d > 0 (and, in the one-measure r^2 variant, |Dn s1 s2| > 0)

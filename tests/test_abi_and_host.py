@@ -429,3 +429,31 @@ def test_synth_thresholds_and_positions():
     pos = synth.synth_positions(5)
     assert pos.tolist() == [1, 501, 1001, 1501, 2001]
     assert synth.prob_to_thr(0.0) == 0 and synth.prob_to_thr(1.0) == 2 ** 64 - 1
+
+
+def test_bound_behind_the_few_missing_codes_class():
+    """csrc/ldx_common.h, snp_class (round 6): the fast epilogue tiers take SNPs with m = n - a - r <= r / 8 missing codes as
+    ordinary because, exactly (rational arithmetic), D' and r^2 never exceed (1 + m1 / r1)(1 + m2 / r2) -- with m <= r / 8:
+    1.266, so 10^4 value fits the 15-bit cell and every guard the kClean variants drop.  Every feasible joint table for n <= 13
+    (the 3 x 3 table of two SNPs with codes ALT / REF / neither exists iff max(0, a1 + a2 - n) <= n11 <= min(a1, a2)), in both
+    sign branches of calc_ld.py:63-76; the bound is attained."""
+    from fractions import Fraction as F
+
+    worst, count = F(0), 0
+    for n in range(2, 14):
+        for a1 in range(1, n):
+            for r1 in range(1, n - a1 + 1):
+                for a2 in range(1, n):
+                    for r2 in range(1, n - a2 + 1):
+                        bound = (1 + F(n - a1 - r1, r1)) * (1 + F(n - a2 - r2, r2))
+                        for n11 in range(max(0, a1 + a2 - n), min(a1, a2) + 1):
+                            dn = n * n11 - a1 * a2
+                            if dn == 0:
+                                continue
+                            b = min(a1 * r2, r1 * a2) if dn > 0 else min(a1 * a2, r1 * r2)      # calc_ld.py:64-65 / :71-72 in counts
+                            dp, rsq = F(abs(dn), b), F(dn * dn, a1 * r1 * a2 * r2)                 # :66 / :73, :87-88
+                            assert dp <= bound and rsq <= bound, (n, a1, r1, a2, r2, n11)
+                            worst = max(worst, dp / bound, rsq / bound)
+                            count += 1
+    assert worst == 1 and count > 50000
+    assert (1 + F(1, 8)) ** 2 < F(127, 100)

@@ -924,7 +924,7 @@ def test_fp32_tier_parks_the_rows_and_columns_of_odd_snps(gpu):
                 codes[r, 5:9] = 2                              # a few missing codes   (ordinary since round 6)
             else:
                 codes[r] = 1
-                codes[r, ::3] = 2                              # no REF allele but a < n   (odd: n11 is not determined)
+                codes[r, ::3] = 2                              # no REF allele, a < n   (degenerate too: int 0 whatever n11 is)
         p = PackedPanel.from_codes(codes)
         for fmt in ("k16", "ld32"):
             got = ld_triangle(p, fmt=fmt, path="fp4")          # no side outputs: the fp32 tier + its fallbacks

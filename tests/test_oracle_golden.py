@@ -243,3 +243,25 @@ def test_golden_generators_load_the_reference_and_reproduce_the_fixtures(tmp_pat
                        stdout=subprocess.DEVNULL, timeout=600)
     for name in GOLDEN_FILES:
         assert (tmp_path / name).read_bytes() == (golden / name).read_bytes(), f"{name}: regen differs"
+
+
+def test_degenerate_snps_give_int_zero_against_any_snp():
+    """csrc/ldx_common.h, kSnpDegenerate (round 6): a SNP with no ALT allele, or with no REF allele -- whatever is missing --
+    gives the int 0 for BOTH values against ANY other SNP in either argument order -- calc_ld.py:66-69 / 73-76 (the bound is 0
+    or -0.0: ZeroDivisionError) and :89-90 -- which is what lets the fp32 tier force such cells without looking at n11.  The
+    oracle's list / zip / count path (itself pinned to the reference) on random partners."""
+    import random
+
+    from oracle import ld_oracle as orc
+
+    rng = random.Random(6)
+    for n in (1, 2, 7, 64, 301):
+        degenerate = [[0] * n, [1] * n, [2] * n, [None] * n, [rng.choice((0, 2)) for _ in range(n)],
+                      [rng.choice((1, 1, 2, None)) for _ in range(n)], [rng.choice((0, 0, None)) for _ in range(n)]]
+        for _ in range(40):
+            other = [rng.choice((0, 1, 1, 0, 2, None)) for _ in range(n)]
+            for d in degenerate:
+                assert d.count(1) == 0 or d.count(0) == 0
+                for got in (orc.calc_ld_lists(d, other), orc.calc_ld_lists(other, d)):
+                    assert got["r_square"] == 0 and isinstance(got["r_square"], int), (d[:8], other[:8], got)
+                    assert got["d_prime"] == 0 and isinstance(got["d_prime"], int), (d[:8], other[:8], got)

@@ -19,7 +19,7 @@ mrows = float(sys.argv[6]) if len(sys.argv) > 6 else 1.0
 p = PackedPanel.from_codes(synth.synth_codes_device(n, h, seed=synth.BENCH_SEED, mono=mono, miss=miss, miss_rows=mrows))
 a = p.acnt[:n].cpu().numpy().view(np.uint32).astype(np.int64)
 r = p.rcnt[:n].cpu().numpy().view(np.uint32).astype(np.int64)
-cls = np.where((a == 0) | ((r == 0) & (a == h)), 1, np.where((r > 0) & (8 * (h - a - r) <= r), 0, 2))
+cls = np.where((a == 0) | (r == 0), 1, np.where(8 * (h - a - r) <= r, 0, 2))   # csrc/ldx_common.h, snp_class
 print("classes: ordinary", int((cls == 0).sum()), "degenerate", int((cls == 1).sum()), "odd", int((cls == 2).sum()))
 want = ld_triangle(p, fmt=fmt, path="popcount")
 got = ld_triangle(p, fmt=fmt, path="fp4")
